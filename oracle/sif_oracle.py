@@ -1,0 +1,346 @@
+"""CPU oracle for the SIF-CNN-SR hot path (ModelB_2 forward/backward + SIF loss terms + Adam).
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain-PyTorch, CPU, fp32 restatement of the reference's
+algorithm.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import it; the product path (the ``*_amd`` package) never does and fails loudly without its HIP
+library.
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the reference itself
+(``/root/reference/model.py`` and the hot-path functions of ``/root/reference/utils.py``) in the
+build container, checks every function below against it on seeded inputs, and commits the resulting
+vectors under ``tests/golden/``; ``tests/test_oracle_golden.py`` re-checks this file against those
+vectors on any machine.
+
+Every function cites the reference file:line it restates (paths relative to /root/reference).
+The restatement is *functional*: parameters and buffers live in plain dicts keyed by the
+reference's ``state_dict`` names, so the 104-key layout (SURVEY.md §8 b) is the oracle's own
+data model.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5        # nn.BatchNorm2d default, model.py:136
+BN_MOMENTUM = 0.1    # nn.BatchNorm2d default, model.py:136
+
+# ----------------------------------------------------------------------------------------------
+# Layer table: (state_dict prefix of the conv, prefix of its BatchNorm, Cin, Cout)
+# Order == reference state_dict order (model.py:596-605 construction order).
+# ----------------------------------------------------------------------------------------------
+CONV_BN_LAYERS = [
+    ("inbloc.bloc.0", "inbloc.bloc.1", 2, 16),
+    ("inbloc.bloc.3", "inbloc.bloc.4", 16, 16),
+    ("db1.resblock.doubleconv.bloc.0", "db1.resblock.doubleconv.bloc.1", 16, 16),
+    ("db1.resblock.doubleconv.bloc.3", "db1.resblock.doubleconv.bloc.4", 16, 16),
+    ("db1.lastconv.0", "db1.lastconv.1", 16, 32),
+    ("db2.resblock.doubleconv.bloc.0", "db2.resblock.doubleconv.bloc.1", 32, 32),
+    ("db2.resblock.doubleconv.bloc.3", "db2.resblock.doubleconv.bloc.4", 32, 32),
+    ("db2.lastconv.0", "db2.lastconv.1", 32, 64),
+    ("db3.resblock.doubleconv.bloc.0", "db3.resblock.doubleconv.bloc.1", 64, 64),
+    ("db3.resblock.doubleconv.bloc.3", "db3.resblock.doubleconv.bloc.4", 64, 64),
+    ("db3.lastconv.0", "db3.lastconv.1", 64, 64),
+    ("ub1.convbloc.bloc.0", "ub1.convbloc.bloc.1", 128, 64),
+    ("ub1.convbloc.bloc.3", "ub1.convbloc.bloc.4", 64, 32),
+    ("ub2.convbloc.bloc.0", "ub2.convbloc.bloc.1", 64, 32),
+    ("ub2.convbloc.bloc.3", "ub2.convbloc.bloc.4", 32, 16),
+    ("ub3.convbloc.bloc.0", "ub3.convbloc.bloc.1", 32, 16),
+    ("ub3.convbloc.bloc.3", "ub3.convbloc.bloc.4", 16, 16),
+]
+OUTLAY = ("outlay", 16, 1)
+
+
+def state_dict_spec():
+    """(name, shape, dtype) for the 104 state_dict entries, in reference order (SURVEY.md §8 b)."""
+    spec = []
+    for conv, bn, cin, cout in CONV_BN_LAYERS:
+        spec.append((conv + ".weight", (cout, cin, 3, 3), torch.float32))
+        spec.append((bn + ".weight", (cout,), torch.float32))
+        spec.append((bn + ".bias", (cout,), torch.float32))
+        spec.append((bn + ".running_mean", (cout,), torch.float32))
+        spec.append((bn + ".running_var", (cout,), torch.float32))
+        spec.append((bn + ".num_batches_tracked", (), torch.int64))
+    spec.append(("outlay.weight", (1, 16, 3, 3), torch.float32))
+    spec.append(("outlay.bias", (1,), torch.float32))
+    return spec
+
+
+def param_names():
+    """The 53 trainable tensors, in ``model.parameters()`` order."""
+    return [n for n, _, _ in state_dict_spec()
+            if not n.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+
+
+def synthetic_state(seed: int) -> "OrderedDict[str, torch.Tensor]":
+    """Formula-generated weights from a bit-stable numpy stream (any machine regenerates them).
+
+    Conv weights ~ N(0, 2/(9 Cin)); BN gamma ~ U(0.5,1.5); beta ~ N(0,0.1); running_mean ~ N(0,0.1);
+    running_var ~ U(0.5,1.5) so that eval mode exercises non-trivial statistics.
+    """
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for name, shape, dtype in state_dict_spec():
+        if name.endswith("num_batches_tracked"):
+            sd[name] = torch.zeros((), dtype=torch.int64)
+        elif name.endswith("running_var"):
+            sd[name] = torch.from_numpy(rs.uniform(0.5, 1.5, shape).astype(np.float32))
+        elif name.endswith("running_mean"):
+            sd[name] = torch.from_numpy((0.1 * rs.standard_normal(shape)).astype(np.float32))
+        elif len(shape) == 4:
+            fan_in = shape[1] * 9
+            sd[name] = torch.from_numpy(
+                (rs.standard_normal(shape) * math.sqrt(2.0 / fan_in)).astype(np.float32))
+        elif name.endswith("bias") and name.startswith("outlay"):
+            sd[name] = torch.from_numpy((0.1 * rs.standard_normal(shape)).astype(np.float32))
+        elif name.endswith(".weight"):           # BN gamma
+            sd[name] = torch.from_numpy(rs.uniform(0.5, 1.5, shape).astype(np.float32))
+        else:                                     # BN beta
+            sd[name] = torch.from_numpy((0.1 * rs.standard_normal(shape)).astype(np.float32))
+    return sd
+
+
+def synthetic_batch(seed: int, batch: int, hr: int = 256):
+    """Seeded (lst, lst_up, ndvi) with the ModisDatasetB.__getitem__ shapes (dataset.py:101-142).
+
+    BASELINE.md §3: lst ~ N(0,1) (B,1,hr/4,hr/4); lst_up = bicubic x4 of lst
+    (F.interpolate, align_corners=False); ndvi ~ N(0,1) clipped to +-3.  numpy stream => bit-stable.
+    """
+    rs = np.random.RandomState(seed)
+    lr = hr // 4
+    lst = torch.from_numpy(rs.standard_normal((batch, 1, lr, lr)).astype(np.float32))
+    ndvi = torch.from_numpy(np.clip(rs.standard_normal((batch, 1, hr, hr)), -3, 3).astype(np.float32))
+    lst_up = F.interpolate(lst, scale_factor=4, mode="bicubic", align_corners=False)
+    return lst, lst_up, ndvi
+
+
+# ----------------------------------------------------------------------------------------------
+# Model (model.py)
+# ----------------------------------------------------------------------------------------------
+def _conv3x3_rep(x, w, b=None):
+    """nn.Conv2d(k=3, stride=1, padding=1, padding_mode='replicate') -- model.py:135,138,507,605."""
+    return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), w, b)
+
+
+def _bn_relu(x, sd, bn, training):
+    """nn.BatchNorm2d (+ running-stat update in training) then the shared nn.ReLU -- model.py:136-137."""
+    y = F.batch_norm(x, sd[bn + ".running_mean"], sd[bn + ".running_var"],
+                     sd[bn + ".weight"], sd[bn + ".bias"],
+                     training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
+    if training:
+        sd[bn + ".num_batches_tracked"] += 1
+    return F.relu(y)
+
+
+def _conv_bn_relu(x, sd, conv, bn, training):
+    return _bn_relu(_conv3x3_rep(x, sd[conv + ".weight"]), sd, bn, training)
+
+
+def _double_conv(x, sd, prefix, training):
+    """DoubleConvolution.forward -- model.py:134-141,159."""
+    x = _conv_bn_relu(x, sd, prefix + ".0", prefix + ".1", training)
+    return _conv_bn_relu(x, sd, prefix + ".3", prefix + ".4", training)
+
+
+def _down_block_pool(x, sd, name, training):
+    """DownBlock_pool.forward -- model.py:504,528-531 with ResidualConnection.forward :311-312."""
+    x = F.avg_pool2d(x, kernel_size=2, stride=2)
+    x = x + _double_conv(x, sd, name + ".resblock.doubleconv.bloc", training)
+    return _conv_bn_relu(x, sd, name + ".lastconv.0", name + ".lastconv.1", training)
+
+
+def _up_block(x, skip, sd, name, training):
+    """UpBlock.forward, bilinear branch -- model.py:205-208,235-248 (F.pad is a no-op here)."""
+    x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    assert x.shape[-2:] == skip.shape[-2:]
+    x = torch.cat([x, skip], dim=1)
+    return _double_conv(x, sd, name + ".convbloc.bloc", training)
+
+
+def modelb2_forward(sd, x, training: bool):
+    """ModelB_2.forward -- model.py:608-645.  ``sd`` is mutated (BN buffers) when ``training``."""
+    s0 = _double_conv(x, sd, "inbloc.bloc", training)
+    s1 = _down_block_pool(s0, sd, "db1", training)
+    s2 = _down_block_pool(s1, sd, "db2", training)
+    s3 = _down_block_pool(s2, sd, "db3", training)
+    u = _up_block(s3, s2, sd, "ub1", training)
+    u = _up_block(u, s1, sd, "ub2", training)
+    u = _up_block(u, s0, sd, "ub3", training)
+    return _conv3x3_rep(u, sd["outlay.weight"], sd["outlay.bias"])
+
+
+# ----------------------------------------------------------------------------------------------
+# SIF loss operators (utils.py, train_model_B_*.py)
+# ----------------------------------------------------------------------------------------------
+def generate_psf_kernel(res: float, mtf_res: float, mtf_fc: float, half_kernel_width=None):
+    """utils.py:1615-1639 -- float64 Gaussian PSF, normalised, cast to float32."""
+    fc = 0.5 / mtf_res
+    sigma = math.sqrt(-math.log(mtf_fc) / 2) / (math.pi * fc)
+    if half_kernel_width is None:
+        half_kernel_width = int(math.ceil(mtf_res / res))
+    h = half_kernel_width
+    k = np.zeros((2 * h + 1, 2 * h + 1))
+    for i in range(h + 1):
+        for j in range(h + 1):
+            dist = res * math.sqrt(i ** 2 + j ** 2)
+            psf = np.exp(-(dist * dist) / (2 * sigma * sigma)) / (sigma * math.sqrt(2 * math.pi))
+            k[h - i, h - j] = psf
+            k[h - i, h + j] = psf
+            k[h + i, h + j] = psf
+            k[h + i, h - j] = psf
+    k = k / np.sum(k)
+    return k.astype(np.float32)
+
+
+def psf_taps_1d(mtf: float, factor: float = 4.0):
+    """Separable factor of generate_psf_kernel(1, factor, mtf): 9 float64 taps summing to 1.
+
+    The 2-D kernel is exp(-(i^2+j^2)/2s^2)/Z = g_i g_j with g normalised (rank-1 to ~1e-8 after
+    the float32 cast); the HIP path uses these taps (cast to fp32) separably.
+    """
+    fc = 0.5 / factor
+    sigma = math.sqrt(-math.log(mtf) / 2) / (math.pi * fc)
+    h = int(math.ceil(factor))
+    g = np.exp(-(np.arange(-h, h + 1, dtype=np.float64) ** 2) / (2 * sigma * sigma))
+    return g / g.sum()
+
+
+def _psf_blur_padded(data, mtf, factor=4.0):
+    """Common head of utils.py:1683-1697 and :1844-1858: reflect pad hw, depthwise 9x9, 'same'."""
+    k = torch.tensor(generate_psf_kernel(1.0, factor, mtf, None), dtype=data.dtype)
+    hw = int((k.shape[-1] - 1) / 2)
+    data = F.pad(data, (hw, hw, hw, hw), mode="reflect")
+    data = F.conv2d(data, k[None, None].expand(data.shape[1], -1, -1, -1),
+                    groups=data.shape[1], padding="same")
+    return data, hw
+
+
+def downscale_LST_SR_to_LR(data, factor: float = 4, mtf: float = 0.1):
+    """utils.py:1671-1706, deci_type='bic': blur on the reflect-padded image, bicubic /4, crop."""
+    data, hw = _psf_blur_padded(data, mtf, factor)
+    data = F.interpolate(data, scale_factor=1 / factor, mode="bicubic")
+    sl = int(hw / factor)
+    return data[:, :, sl:data.shape[-2] - sl, sl:data.shape[-1] - sl]
+
+
+def get_output_ftm(data, factor: float = 4, mtf: float = 0.1):
+    """utils.py:1833-1860: reflect-border Gaussian low-pass, same size as the input."""
+    data, hw = _psf_blur_padded(data, mtf, factor)
+    return data[:, :, hw:data.shape[-2] - hw, hw:data.shape[-1] - hw]
+
+
+# train_model_B_predef_filters.py:38-42 (N-S, E-W and the two diagonals)
+SOBEL_FILTERS = [[[1, 2, 1], [0, 0, 0], [-1, -2, -1]],
+                 [[1, 0, -1], [2, 0, -2], [1, 0, -1]],
+                 [[2, 1, 0], [1, 0, -1], [0, -1, -2]],
+                 [[0, 1, 2], [-1, 0, 1], [-2, -1, 0]]]
+
+
+def sobel_bank(x):
+    """train_model_B_predef_filters.py:120-128: F.conv2d(x, (4,1,3,3), padding='same') (zero pad)."""
+    f = torch.tensor(SOBEL_FILTERS, dtype=torch.float32)[:, None]
+    return F.conv2d(x, f, padding="same")
+
+
+def huber(a, b):
+    """nn.HuberLoss(reduction='mean', delta=1.0) -- train_model_B_gradFTM.py:454."""
+    return F.huber_loss(a, b, reduction="mean", delta=1.0)
+
+
+def sr2_loss(sr, lst, ndvi, mean, std, alpha, gamma):
+    """train_model_B_gradFTM.py:99-117 -> (ds_loss, percep_loss, loss)."""
+    sr_un = sr * std + mean
+    down = downscale_LST_SR_to_LR(sr_un)
+    down = (down - mean) / std
+    ds = huber(down, lst)
+    g_lst = sr - get_output_ftm(sr, mtf=0.25)
+    g_ndvi = ndvi - get_output_ftm(ndvi, mtf=0.25)
+    pl = huber(g_lst, gamma * g_ndvi)
+    return ds, pl, alpha * ds + (1 - alpha) * pl
+
+
+def sr1_loss(sr, lst, ndvi, mean, std, alpha, gamma):
+    """train_model_B_predef_filters.py:111-133 -> (ds_loss, percep_loss, loss)."""
+    sr_un = sr * std + mean
+    down = downscale_LST_SR_to_LR(sr_un)
+    down = (down - mean) / std
+    ds = huber(down, lst)
+    pl = huber(sobel_bank(sr), gamma * sobel_bank(ndvi))
+    return ds, pl, alpha * ds + (1 - alpha) * pl
+
+
+LOSSES = {"sr2": sr2_loss, "sr1": sr1_loss}
+
+
+# ----------------------------------------------------------------------------------------------
+# Train step (train_model_B_gradFTM.py:86-121 / train_model_B_predef_filters.py:98-137)
+# ----------------------------------------------------------------------------------------------
+def forward_backward(sd, lst, lst_up, ndvi, mean, std, alpha, gamma, kind="sr2"):
+    """One fwd + loss + backward in training mode.  Returns (sr, (ds, pl, loss), grads dict).
+
+    ``sd`` BN buffers are updated exactly as ``model.train(); model(x)`` would.
+    """
+    names = param_names()
+    leaves = {n: sd[n].detach().clone().requires_grad_(True) for n in names}
+    work = OrderedDict((k, leaves.get(k, v)) for k, v in sd.items())
+    x = torch.cat((lst_up, ndvi), dim=1)                       # :94
+    sr = modelb2_forward(work, x, training=True)               # :96
+    ds, pl, loss = LOSSES[kind](sr, lst, ndvi, mean, std, alpha, gamma)
+    grads = torch.autograd.grad(loss, [leaves[n] for n in names])
+    for k in sd:                                               # carry BN buffer updates back
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            sd[k] = work[k].detach()
+    return sr.detach(), (ds.detach(), pl.detach(), loss.detach()), dict(zip(names, grads))
+
+
+class AdamState:
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) restated
+    (train_model_B_gradFTM.py:453); single-tensor formula of torch/optim/adam.py."""
+
+    def __init__(self, names, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.t = 0
+        self.m = {n: None for n in names}
+        self.v = {n: None for n in names}
+
+    def step(self, sd, grads):
+        self.t += 1
+        bc1 = 1 - self.b1 ** self.t
+        bc2 = 1 - self.b2 ** self.t
+        for n, g in grads.items():
+            if self.m[n] is None:
+                self.m[n] = torch.zeros_like(g)
+                self.v[n] = torch.zeros_like(g)
+            # same op sequence as torch.optim.adam._single_tensor_adam (bit-exact on CPU)
+            self.m[n].lerp_(g, 1 - self.b1)
+            self.v[n].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            denom = (self.v[n].sqrt() / (bc2 ** 0.5)).add_(self.eps)
+            sd[n] = sd[n].clone().addcdiv_(self.m[n], denom, value=-(self.lr / bc1))
+
+
+def train_step(sd, adam, lst, lst_up, ndvi, mean, std, alpha, gamma, kind="sr2"):
+    """a11 / a12 of SURVEY.md §8: fwd, loss, backward, Adam.  Returns (ds, pl, loss) floats."""
+    _, losses, grads = forward_backward(sd, lst, lst_up, ndvi, mean, std, alpha, gamma, kind)
+    adam.step(sd, grads)
+    return tuple(float(v) for v in losses)
+
+
+def predict_tiles(sd, lst_up, ndvi, mean, std):
+    """predict.py:100-101: eval-mode forward, de-normalised output."""
+    with torch.inference_mode():
+        return modelb2_forward(sd, torch.cat((lst_up, ndvi), dim=1), training=False) * std + mean
+
+
+# ----------------------------------------------------------------------------------------------
+# digests used by the golden fixtures
+# ----------------------------------------------------------------------------------------------
+def digest(t: torch.Tensor, nsamples: int = 64):
+    """Order-independent + sampled summary of a tensor (float64 accumulation)."""
+    d = t.detach().double().flatten()
+    n = d.numel()
+    idx = torch.linspace(0, n - 1, min(nsamples, n)).long()
+    return {"shape": list(t.shape), "sum": float(d.sum()), "abs_sum": float(d.abs().sum()),
+            "l2": float(d.norm()), "samples": [float(v) for v in d[idx]]}
