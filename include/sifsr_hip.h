@@ -1,0 +1,121 @@
+/* sifsr_hip.h -- C ABI of libsifsr_hip.so: the SIF-CNN-SR hot path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only: every `float*`
+ * below is a DEVICE pointer (fp32), `stream` is a hipStream_t passed as void*, all tensors are
+ * dense.  Functions only enqueue work on `stream` (no allocation, no synchronisation) and
+ * return 0 on success, a SIFSR_ERR_* code (1001..1003) for bad arguments, or the hipError_t of a
+ * failed launch.  The reference is pure Python on PyTorch; each entry point names the reference
+ * interface (path relative to the reference repo root, file:line) whose ATen dispatch it replaces.
+ * The ctypes binding a maintainer adds on the reference side is shown in INTEGRATION.md.
+ *
+ * Layouts: model input  x  (B,2,H,W) NCHW  == torch.cat((lst_up, ndvi), 1), train_model_B_gradFTM.py:94
+ *          model output sr (B,1,H,W) NCHW, model.py:645
+ *          params: ONE flat fp32 buffer of 282,705 floats in `model.parameters()` order
+ *                  (conv OIHW weights / BN weight / BN bias per layer, then outlay.weight, outlay.bias)
+ *          running: flat fp32 [per BN layer: running_mean(C), running_var(C)], nbt: int64[17]
+ *          activations between kernels: NHWC fp32 (internal).
+ * H and W must be multiples of 128 for the model entry points (4 resolution levels x 16-pixel tiles)
+ * and multiples of 32 for the loss operators.
+ */
+#ifndef SIFSR_HIP_H
+#define SIFSR_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+#define SIFSR_API extern "C" __attribute__((visibility("default")))
+#else
+#define SIFSR_API
+#endif
+
+/* ---- introspection (host only, no GPU touched) -------------------------------------------- */
+SIFSR_API int sifsr_abi_version(void);
+SIFSR_API int sifsr_num_params(void);   /* 282705 */
+SIFSR_API int sifsr_num_running(void);  /* 1184 = 2 * 592 channels */
+/* out[17][8] = {cin, cout, level, w_off, gamma_off, beta_off, run_off, ch_off}; returns 17 */
+SIFSR_API int sifsr_layer_table(int* out, int capacity_rows);
+
+/* ---- ModelB_2 (model.py:533-645) ------------------------------------------------------------ */
+SIFSR_API size_t sifsr_model_workspace_bytes(int B, int H, int W, int training);
+/* ModelB_2.forward, model.py:608-645.  training != 0: batch statistics, running-stat update
+ * (momentum, unbiased var) and nbt += 1, activations kept in `workspace` for sifsr_model_backward;
+ * training == 0: model.eval() semantics (running statistics), predict.py:68,100. */
+SIFSR_API int sifsr_model_forward(const float* x, float* sr, const float* params, float* running, long long* nbt,
+                                  void* workspace, size_t workspace_bytes, int B, int H, int W, int training,
+                                  float momentum, float eps, void* stream);
+/* autograd transpose of the above (loss.backward(), train_model_B_gradFTM.py:119): dsr = dL/dsr;
+ * writes ALL 282,705 gradients ("=" semantics) into grads (same layout as params). */
+SIFSR_API int sifsr_model_backward(const float* x, const float* dsr, const float* params, float* grads,
+                                   void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
+
+/* ---- 3x3 convolution pieces (nn.Conv2d(k=3,padding=1,padding_mode='replicate'), model.py:135,138,507) */
+/* OIHW -> MFMA fragment order (forward operand and transposed+flipped dgrad operand), 9*cin*cout floats each */
+SIFSR_API int sifsr_pack_conv_weights(const float* w_oihw, int cin, int cout, float* wfwd, float* wdgrad, void* stream);
+/* y = conv(cat([a0, a1], C)), a_i = relu(src_i*scale_i+shift_i) if scale_i != NULL else src_i (NHWC, C_i % 16 == 0;
+ * src1 may be NULL).  stat_partials: NULL or [B*(H/16)*(W/16)][cout][2] per-tile (sum, sumsq) of y. */
+SIFSR_API int sifsr_conv3x3_fwd(const float* src0, int C0, const float* scale0, const float* shift0,
+                                const float* src1, int C1, const float* scale1, const float* shift1,
+                                const float* wfwd, float* y, int cout, float* stat_partials, int B, int H, int W,
+                                void* stream);
+/* g_in = conv^T(dy) incl. replicate-border fold; channels [0,C0) -> g0, [C0,cin) -> g1 (NULL if unused);
+ * addend (cin channels, may be NULL) is added to g0 (needs g1 == NULL). */
+SIFSR_API int sifsr_conv3x3_dgrad(const float* dy, int cout, const float* wdgrad, const float* w_oihw, int cin,
+                                  float* g0, int C0, float* g1, int C1, const float* addend, int B, int H, int W,
+                                  void* stream);
+SIFSR_API size_t sifsr_conv3x3_wgrad_scratch_floats(int cin, int cout, int nblk);
+/* dw (OIHW) = sum_pixels dy (x) a_in; deterministic 2-stage reduction through `scratch`. */
+SIFSR_API int sifsr_conv3x3_wgrad(const float* src0, int C0, const float* scale0, const float* shift0,
+                                  const float* src1, int C1, const float* scale1, const float* shift1,
+                                  const float* dy, int cout, float* scratch, int nblk, float* dw, int B, int H, int W,
+                                  void* stream);
+/* inbloc.bloc.0, Conv2d(2,16): x NCHW -> y NHWC (model.py:596) */
+SIFSR_API int sifsr_conv_in_fwd(const float* x, const float* w, float* y, float* stat_partials, int B, int H, int W, void* stream);
+SIFSR_API int sifsr_conv_in_wgrad(const float* x, const float* dy, float* scratch, int nblk, float* dw, int B, int H, int W, void* stream);
+/* outlay, Conv2d(16,1)+bias: y NHWC (BN+ReLU folded) -> sr NCHW (model.py:605); dwb = [144 weight | 1 bias] */
+SIFSR_API int sifsr_conv_out_fwd(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
+                                 float* sr, int B, int H, int W, void* stream);
+SIFSR_API int sifsr_conv_out_dgrad(const float* dsr, const float* w, float* g, int B, int H, int W, void* stream);
+SIFSR_API int sifsr_conv_out_wgrad(const float* y, const float* scale, const float* shift, const float* dsr, float* scratch,
+                                   int nblk, float* dwb, int B, int H, int W, void* stream);
+
+/* ---- BatchNorm2d (model.py:136,139,508; eps 1e-5, momentum 0.1) ------------------------------ */
+SIFSR_API int sifsr_bn_finalize(const float* stat_partials, int nblk, int C, double count, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* g = dL/d relu(bn(y)) -> dgamma, dbeta, dy = dL/dy; partials: >= nblk*C*2 floats; c1,c0: C floats scratch */
+SIFSR_API int sifsr_bn_relu_bwd(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, int C, size_t npix, float* partials, int nblk, float* dgamma,
+                                float* dbeta, float* c1, float* c0, float* dy, void* stream);
+
+/* ---- resampling (NHWC; scale == NULL: input used as stored) ---------------------------------- */
+SIFSR_API int sifsr_bnrelu_pool2(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W, int C, void* stream); /* AvgPool2d(2,2), model.py:504 */
+SIFSR_API int sifsr_bnrelu_add(const float* p, const float* y, const float* scale, const float* shift, float* out, int C, size_t npix, void* stream); /* model.py:311-312 */
+SIFSR_API int sifsr_bnrelu_up2x(const float* y, const float* scale, const float* shift, float* out, int B, int Hin, int Win, int C, void* stream); /* Upsample(x2,bilinear,align_corners=True), model.py:207 */
+SIFSR_API int sifsr_pool2_bwd(const float* gp, float* g, int B, int H, int W, int C, int accumulate, void* stream);
+SIFSR_API int sifsr_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, void* stream);
+
+/* ---- SIF loss operators on (B,1,H,W) images --------------------------------------------------- */
+/* taps9: 9 HOST floats, the separable factor of generate_psf_kernel (utils.py:1615-1639) */
+SIFSR_API int sifsr_gauss9_reflect_fwd(const float* x, const float* taps9, float* out, int B, int H, int W, void* stream);   /* get_output_ftm, utils.py:1833-1860 */
+SIFSR_API int sifsr_gauss9_reflect_bwd(const float* g, const float* taps9, float* gx, int B, int H, int W, void* stream);
+SIFSR_API int sifsr_gauss9_decimate4_fwd(const float* x, const float* taps9, float* out_lr, int B, int H, int W, void* stream); /* downscale_LST_SR_to_LR, utils.py:1671-1706 */
+SIFSR_API int sifsr_gauss9_decimate4_bwd(const float* g_lr, const float* taps9, float* gx, int B, int H, int W, void* stream);
+SIFSR_API int sifsr_sobel4_fwd(const float* x, float* out_b4hw, int B, int H, int W, void* stream);   /* train_model_B_predef_filters.py:120-128 */
+SIFSR_API int sifsr_sobel4_bwd(const float* g_b4hw, float* gx, int B, int H, int W, void* stream);
+SIFSR_API int sifsr_huber_partial_blocks(size_t n);
+/* out[0] = mean huber_1(a - bscale*b), nn.HuberLoss(delta=1), train_model_B_gradFTM.py:454 */
+SIFSR_API int sifsr_huber_fwd(const float* a, const float* b, float bscale, size_t n, float* partials, float* out, void* stream);
+SIFSR_API int sifsr_huber_bwd(const float* a, const float* b, float bscale, const float* gout, size_t n, float* ga, void* stream);
+SIFSR_API size_t sifsr_sif_loss_workspace_bytes(int kind, int B, int H, int W);
+/* kind 2: SR2 loss, train_model_B_gradFTM.py:99-117; kind 1: SR1, train_model_B_predef_filters.py:111-133.
+ * losses3 (device) = {ds_loss, percep_loss, alpha*ds + (1-alpha)*percep}; dsr (may be NULL) = d loss / d sr. */
+SIFSR_API int sifsr_sif_loss(int kind, const float* sr, const float* lst, const float* ndvi, int B, int H, int W,
+                             float mean, float std, float alpha, float gamma, const float* taps_ds9,
+                             const float* taps_ftm9, void* workspace, size_t workspace_bytes, float* losses3,
+                             float* dsr, void* stream);
+
+/* ---- optimizer: torch.optim.Adam on the flat buffer (train_model_B_gradFTM.py:453,121) -------- */
+SIFSR_API int sifsr_adam_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                              void* stream);
+
+#endif /* SIFSR_HIP_H */

@@ -1,0 +1,223 @@
+// Training / eval BatchNorm2d pieces (nn.BatchNorm2d defaults: eps 1e-5, momentum 0.1, biased batch
+// variance for normalisation, unbiased for running_var -- model.py:136,139,508).
+//
+// Forward statistics are produced as per-workgroup (sum, sumsq) partials by the conv kernels'
+// epilogues; bn_finalize reduces them in float64 (order-stable, no float atomics), folds
+// gamma/beta/mean/invstd into scale/shift for the consumer's load path and updates running stats.
+// Backward: dz = g * [z > 0];  dgamma = sum dz*xhat;  dbeta = sum dz;
+//           dy = gamma*invstd * (dz - dbeta/N - xhat*dgamma/N) = scale*dz + c1*y + c0.
+#include "edge_conv.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* run_mean,
+                                                          float* run_var, float momentum, float eps, float* mean,
+                                                          float* invstd, float* scale, float* shift) {
+  __shared__ double r1[256], r2[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = tid; k < nblk; k += 256) {
+    s1 += (double)partials[((size_t)k * C + c) * 2 + 0];
+    s2 += (double)partials[((size_t)k * C + c) * 2 + 1];
+  }
+  r1[tid] = s1; r2[tid] = s2;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) { r1[tid] += r1[tid + st]; r2[tid] += r2[tid + st]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double m = r1[0] / count;
+    double var = r2[0] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float istd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * istd;
+    mean[c] = (float)m;
+    invstd[c] = istd;
+    scale[c] = sc;
+    shift[c] = fmaf(-(float)m, sc, beta[c]);
+    if (run_mean != nullptr) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+  }
+}
+
+struct BnEvalTable { int gamma_off[SIFSR_NUM_BN_LAYERS], beta_off[SIFSR_NUM_BN_LAYERS], run_off[SIFSR_NUM_BN_LAYERS],
+                         ch_off[SIFSR_NUM_BN_LAYERS], cout[SIFSR_NUM_BN_LAYERS]; };
+
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ params, const float* __restrict__ running, float eps,
+                                      float* scale, float* shift, const BnEvalTable tb) {
+  const int l = blockIdx.x, c = threadIdx.x;
+  if (c >= tb.cout[l]) return;
+  const float rm = running[tb.run_off[l] + c], rv = running[tb.run_off[l] + tb.cout[l] + c];
+  const float sc = params[tb.gamma_off[l] + c] / sqrtf(rv + eps);
+  scale[tb.ch_off[l] + c] = sc;
+  shift[tb.ch_off[l] + c] = fmaf(-rm, sc, params[tb.beta_off[l] + c]);
+}
+
+// per-workgroup partial (sum dz, sum dz*xhat) per channel
+template <int C>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, size_t npix,
+                                                            float* __restrict__ partials) {
+  constexpr int Q = C / 4;          // channel quads
+  constexpr int PP = 256 / Q;       // pixels per pass per workgroup
+  __shared__ float red[256][8];
+  const int tid = threadIdx.x, c4 = tid % Q, pl = tid / Q;
+  const float4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4), mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4);
+  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  for (size_t p = (size_t)blockIdx.x * PP + pl; p < npix; p += (size_t)gridDim.x * PP) {
+    const float4 yv = ld4(y + p * C + 4 * c4), gv = ld4(g + p * C + 4 * c4);
+    const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float dz = fmaf(yy[j], scv[j], shv[j]) > 0.f ? gg[j] : 0.f;
+      a1[j] += dz;
+      a2[j] = fmaf(dz, (yy[j] - muv[j]) * isv[j], a2[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[tid][j] = a1[j]; red[tid][4 + j] = a2[j]; }
+  __syncthreads();
+  // tree over the PP pixel lanes that share a channel quad (threads c4, c4+Q, c4+2Q, ...)
+  for (int st = PP / 2; st > 0; st >>= 1) {
+    if (pl < st) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[tid][j] += red[tid + st * Q][j];
+    }
+    __syncthreads();
+  }
+  if (pl == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      partials[((size_t)blockIdx.x * C + 4 * c4 + j) * 2 + 0] = red[tid][j];
+      partials[((size_t)blockIdx.x * C + 4 * c4 + j) * 2 + 1] = red[tid][4 + j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
+                                                              double count, const float* __restrict__ scale,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float* dgamma,
+                                                              float* dbeta, float* c1, float* c0) {
+  __shared__ double r1[256], r2[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = tid; k < nblk; k += 256) {
+    s1 += (double)partials[((size_t)k * C + c) * 2 + 0];
+    s2 += (double)partials[((size_t)k * C + c) * 2 + 1];
+  }
+  r1[tid] = s1; r2[tid] = s2;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) { r1[tid] += r1[tid + st]; r2[tid] += r2[tid + st]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double db = r1[0], dg = r2[0];
+    dbeta[c] = (float)db;
+    dgamma[c] = (float)dg;
+    const double k1 = -(double)scale[c] * (double)invstd[c] * dg / count;
+    c1[c] = (float)k1;
+    c0[c] = (float)(-(double)scale[c] * db / count - k1 * (double)mean[c]);
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ c1, const float* __restrict__ c0,
+                                                           size_t nquads, float* __restrict__ dy) {
+  constexpr int Q = C / 4;
+  const int c4 = threadIdx.x % Q;   // 256 % Q == 0 and grid stride is a multiple of 256
+  const float4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4), k1 = ld4(c1 + 4 * c4), k0 = ld4(c0 + 4 * c4);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nquads; e += (size_t)gridDim.x * 256) {
+    const float4 yv = ld4(y + e * 4), gv = ld4(g + e * 4);
+    float4 o;
+    o.x = fmaf(sc.x, fmaf(yv.x, sc.x, sh.x) > 0.f ? gv.x : 0.f, fmaf(k1.x, yv.x, k0.x));
+    o.y = fmaf(sc.y, fmaf(yv.y, sc.y, sh.y) > 0.f ? gv.y : 0.f, fmaf(k1.y, yv.y, k0.y));
+    o.z = fmaf(sc.z, fmaf(yv.z, sc.z, sh.z) > 0.f ? gv.z : 0.f, fmaf(k1.z, yv.z, k0.z));
+    o.w = fmaf(sc.w, fmaf(yv.w, sc.w, sh.w) > 0.f ? gv.w : 0.f, fmaf(k1.w, yv.w, k0.w));
+    st4(dy + e * 4, o);
+  }
+}
+
+__global__ void nbt_increment_kernel(long long* nbt, int n) {
+  const int i = threadIdx.x;
+  if (i < n) nbt[i] += 1;
+}
+
+}  // namespace
+
+int launch_bn_finalize(const float* partials, int nblk, int C, double count, const float* gamma, const float* beta,
+                       float* run_mean, float* run_var, float momentum, float eps, float* mean, float* invstd,
+                       float* scale, float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, partials, nblk, C, count, gamma, beta, run_mean,
+                     run_var, momentum, eps, mean, invstd, scale, shift);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_bn_eval_coeffs(const float* params, const float* running, float eps, float* scale, float* shift, hipStream_t s) {
+  const NetTable& nt = sifsr_net();
+  BnEvalTable tb;
+  for (int l = 0; l < SIFSR_NUM_BN_LAYERS; ++l) {
+    tb.gamma_off[l] = nt.L[l].gamma_off; tb.beta_off[l] = nt.L[l].beta_off; tb.run_off[l] = nt.L[l].run_off;
+    tb.ch_off[l] = nt.L[l].ch_off; tb.cout[l] = nt.L[l].cout;
+  }
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(SIFSR_NUM_BN_LAYERS), dim3(64), 0, s, params, running, eps, scale, shift, tb);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_bn_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, int C, size_t npix, float* partials, int nblk, hipStream_t s) {
+  switch (C) {
+    case 16: hipLaunchKernelGGL((bn_bwd_reduce_kernel<16>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials); break;
+    case 32: hipLaunchKernelGGL((bn_bwd_reduce_kernel<32>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials); break;
+    case 64: hipLaunchKernelGGL((bn_bwd_reduce_kernel<64>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials); break;
+    default: return SIFSR_ERR_SHAPE;
+  }
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_bn_bwd_finalize(const float* partials, int nblk, int C, double count, const float* scale, const float* mean,
+                           const float* invstd, float* dgamma, float* dbeta, float* c1, float* c0, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, partials, nblk, C, count, scale, mean, invstd,
+                     dgamma, dbeta, c1, c0);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, const float* c1,
+                        const float* c0, int C, size_t npix, float* dy, hipStream_t s) {
+  const size_t nquads = npix * (size_t)C / 4;
+  size_t blocks = (nquads + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  switch (C) {
+    case 16: hipLaunchKernelGGL((bn_bwd_apply_kernel<16>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, c1, c0, nquads, dy); break;
+    case 32: hipLaunchKernelGGL((bn_bwd_apply_kernel<32>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, c1, c0, nquads, dy); break;
+    case 64: hipLaunchKernelGGL((bn_bwd_apply_kernel<64>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, c1, c0, nquads, dy); break;
+    default: return SIFSR_ERR_SHAPE;
+  }
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_nbt_increment(long long* nbt, int n, hipStream_t s) {
+  hipLaunchKernelGGL(nbt_increment_kernel, dim3(1), dim3(64), 0, s, nbt, n);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}

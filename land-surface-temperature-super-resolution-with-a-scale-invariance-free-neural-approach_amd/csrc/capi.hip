@@ -1,0 +1,177 @@
+// extern "C" surface of libsifsr_hip.so -- see include/sifsr_hip.h for the contract.
+#include "../../include/sifsr_hip.h"
+
+#include "engine.h"
+
+#define S(stream) ((hipStream_t)(stream))
+
+static ConvSrc mk_src(const float* p, int C, const float* sc, const float* sh) {
+  ConvSrc s; s.ptr = p; s.scale = p ? sc : nullptr; s.shift = p ? sh : nullptr; s.C = p ? C : 0; s.coff = 0; s.nq = p ? C / 16 : 0;
+  return s;
+}
+
+int sifsr_abi_version(void) { return 1; }
+int sifsr_num_params(void) { return sifsr_net().total_params; }
+int sifsr_num_running(void) { return sifsr_net().total_running; }
+int sifsr_layer_table(int* out, int capacity_rows) {
+  const NetTable& nt = sifsr_net();
+  for (int l = 0; l < SIFSR_NUM_BN_LAYERS && l < capacity_rows; ++l) {
+    const LayerInfo& L = nt.L[l];
+    int* r = out + 8 * l;
+    r[0] = L.cin; r[1] = L.cout; r[2] = L.level; r[3] = L.w_off; r[4] = L.gamma_off; r[5] = L.beta_off; r[6] = L.run_off; r[7] = L.ch_off;
+  }
+  return SIFSR_NUM_BN_LAYERS;
+}
+
+size_t sifsr_model_workspace_bytes(int B, int H, int W, int training) {
+  WsLayout l;
+  if (sifsr_layout(B, H, W, training, &l) != SIFSR_OK) return 0;
+  return l.total * sizeof(float);
+}
+int sifsr_model_forward(const float* x, float* sr, const float* params, float* running, long long* nbt, void* workspace,
+                        size_t workspace_bytes, int B, int H, int W, int training, float momentum, float eps, void* stream) {
+  return sifsr_engine_forward(x, sr, params, running, nbt, (float*)workspace, workspace_bytes / sizeof(float), B, H, W,
+                              training, momentum, eps, S(stream));
+}
+int sifsr_model_backward(const float* x, const float* dsr, const float* params, float* grads, void* workspace,
+                         size_t workspace_bytes, int B, int H, int W, void* stream) {
+  return sifsr_engine_backward(x, dsr, params, grads, (float*)workspace, workspace_bytes / sizeof(float), B, H, W, S(stream));
+}
+
+int launch_pack_weights_one(const float* w, int cin, int cout, float* wfwd, float* wdg, hipStream_t s);
+int sifsr_pack_conv_weights(const float* w_oihw, int cin, int cout, float* wfwd, float* wdgrad, void* stream) {
+  if (cin % 16 || cout % 16) return SIFSR_ERR_SHAPE;
+  return launch_pack_weights_one(w_oihw, cin, cout, wfwd, wdgrad, S(stream));
+}
+
+int sifsr_conv3x3_fwd(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
+                      const float* scale1, const float* shift1, const float* wfwd, float* y, int cout,
+                      float* stat_partials, int B, int H, int W, void* stream) {
+  if (!src0 || C0 % 16 || (src1 && C1 % 16)) return SIFSR_ERR_SHAPE;
+  ConvArgs a;
+  a.src[0] = mk_src(src0, C0, scale0, shift0);
+  a.src[1] = mk_src(src1, C1, scale1, shift1);
+  a.dst[0].ptr = y; a.dst[0].C = cout; a.dst[0].coff = 0; a.dst[1] = a.dst[0];
+  a.wpack = wfwd; a.addend = nullptr; a.addC = 0; a.stat_partials = stat_partials; a.dst_split = cout / 16;
+  a.B = B; a.H = H; a.W = W; a.NQ = a.src[0].nq + a.src[1].nq;
+  return launch_conv3x3_mfma(a, cout, 0, S(stream));
+}
+
+int sifsr_conv3x3_dgrad(const float* dy, int cout, const float* wdgrad, const float* w_oihw, int cin, float* g0, int C0,
+                        float* g1, int C1, const float* addend, int B, int H, int W, void* stream) {
+  if (cout % 16 || cin % 16 || C0 % 16 || (g1 && (C1 % 16 || C0 + C1 != cin)) || (!g1 && C0 != cin) || (addend && g1))
+    return SIFSR_ERR_SHAPE;
+  ConvArgs a;
+  a.src[0] = mk_src(dy, cout, nullptr, nullptr); a.src[1] = mk_src(nullptr, 0, nullptr, nullptr);
+  a.dst[0].ptr = g0; a.dst[0].C = C0; a.dst[0].coff = 0;
+  a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
+  a.wpack = wdgrad; a.addend = addend; a.addC = cin; a.stat_partials = nullptr; a.dst_split = C0 / 16;
+  a.B = B; a.H = H; a.W = W; a.NQ = cout / 16;
+  int rc = launch_conv3x3_mfma(a, cin, 1, S(stream));
+  if (rc) return rc;
+  return launch_dgrad_border_fix(dy, cout, w_oihw, cin, g0, C0, 0, C0, g1 ? g1 : g0, g1 ? C1 : C0, 0, B, H, W, S(stream));
+}
+
+size_t sifsr_conv3x3_wgrad_scratch_floats(int cin, int cout, int nblk) { return (size_t)nblk * wgrad_slab_floats(cin, cout); }
+
+int sifsr_conv3x3_wgrad(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
+                        const float* scale1, const float* shift1, const float* dy, int cout, float* scratch, int nblk,
+                        float* dw, int B, int H, int W, void* stream) {
+  if (!src0 || C0 % 16 || (src1 && C1 % 16)) return SIFSR_ERR_SHAPE;
+  WgradArgs a;
+  a.src[0] = mk_src(src0, C0, scale0, shift0);
+  a.src[1] = mk_src(src1, C1, scale1, shift1);
+  a.dy = dy; a.slabs = scratch; a.B = B; a.H = H; a.W = W;
+  a.NQ = a.src[0].nq + a.src[1].nq;
+  a.ntiles = B * (H / 8) * (W / 16);
+  const int cin = 16 * a.NQ;
+  if (nblk > a.ntiles) nblk = a.ntiles;
+  int rc = launch_conv3x3_wgrad(a, cin, cout, nblk, S(stream));
+  if (rc) return rc;
+  return launch_wgrad_reduce(scratch, nblk, cin, cout, dw, S(stream));
+}
+
+int sifsr_conv_in_fwd(const float* x, const float* w, float* y, float* stat_partials, int B, int H, int W, void* stream) {
+  return launch_conv_in_fwd(x, w, y, stat_partials, B, H, W, S(stream));
+}
+int sifsr_conv_in_wgrad(const float* x, const float* dy, float* scratch, int nblk, float* dw, int B, int H, int W, void* stream) {
+  return launch_conv_in_wgrad(x, dy, scratch, nblk, dw, B, H, W, S(stream));
+}
+int sifsr_conv_out_fwd(const float* y, const float* scale, const float* shift, const float* w, const float* bias, float* sr,
+                       int B, int H, int W, void* stream) {
+  return launch_conv_out_fwd(y, scale, shift, w, bias, sr, B, H, W, S(stream));
+}
+int sifsr_conv_out_dgrad(const float* dsr, const float* w, float* g, int B, int H, int W, void* stream) {
+  return launch_conv_out_dgrad(dsr, w, g, B, H, W, S(stream));
+}
+int sifsr_conv_out_wgrad(const float* y, const float* scale, const float* shift, const float* dsr, float* scratch, int nblk,
+                         float* dwb, int B, int H, int W, void* stream) {
+  return launch_conv_out_wgrad(y, scale, shift, dsr, scratch, nblk, dwb, dwb + 144, B, H, W, S(stream));
+}
+
+int sifsr_bn_finalize(const float* stat_partials, int nblk, int C, double count, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                      float* scale, float* shift, void* stream) {
+  return launch_bn_finalize(stat_partials, nblk, C, count, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                            invstd, scale, shift, S(stream));
+}
+int sifsr_bn_relu_bwd(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
+                      const float* invstd, int C, size_t npix, float* partials, int nblk, float* dgamma, float* dbeta,
+                      float* c1, float* c0, float* dy, void* stream) {
+  int rc = launch_bn_bwd_reduce(g, y, scale, shift, mean, invstd, C, npix, partials, nblk, S(stream));
+  if (rc) return rc;
+  rc = launch_bn_bwd_finalize(partials, nblk, C, (double)npix, scale, mean, invstd, dgamma, dbeta, c1, c0, S(stream));
+  if (rc) return rc;
+  return launch_bn_bwd_apply(g, y, scale, shift, c1, c0, C, npix, dy, S(stream));
+}
+
+int sifsr_bnrelu_pool2(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W, int C, void* stream) {
+  return launch_bnrelu_pool2(y, scale, shift, out, B, H, W, C, S(stream));
+}
+int sifsr_bnrelu_add(const float* p, const float* y, const float* scale, const float* shift, float* out, int C, size_t npix, void* stream) {
+  return launch_bnrelu_add(p, y, scale, shift, out, C, npix, S(stream));
+}
+int sifsr_bnrelu_up2x(const float* y, const float* scale, const float* shift, float* out, int B, int Hin, int Win, int C, void* stream) {
+  return launch_bnrelu_up2x(y, scale, shift, out, B, Hin, Win, C, S(stream));
+}
+int sifsr_pool2_bwd(const float* gp, float* g, int B, int H, int W, int C, int accumulate, void* stream) {
+  return launch_pool2_bwd(gp, g, B, H, W, C, accumulate, S(stream));
+}
+int sifsr_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, void* stream) {
+  return launch_up2x_bwd(gu, g, B, Hin, Win, C, S(stream));
+}
+
+int sifsr_gauss9_reflect_fwd(const float* x, const float* taps9, float* out, int B, int H, int W, void* stream) {
+  return launch_blur_fwd(x, taps9, out, B, H, W, S(stream));
+}
+int sifsr_gauss9_reflect_bwd(const float* g, const float* taps9, float* gx, int B, int H, int W, void* stream) {
+  return launch_blur_bwd(g, taps9, gx, B, H, W, S(stream));
+}
+int sifsr_gauss9_decimate4_fwd(const float* x, const float* taps9, float* out_lr, int B, int H, int W, void* stream) {
+  return launch_blurdec_fwd(x, taps9, out_lr, B, H, W, S(stream));
+}
+int sifsr_gauss9_decimate4_bwd(const float* g_lr, const float* taps9, float* gx, int B, int H, int W, void* stream) {
+  return launch_blurdec_bwd(g_lr, taps9, gx, B, H, W, S(stream));
+}
+int sifsr_sobel4_fwd(const float* x, float* out_b4hw, int B, int H, int W, void* stream) { return launch_sobel_fwd(x, out_b4hw, B, H, W, S(stream)); }
+int sifsr_sobel4_bwd(const float* g_b4hw, float* gx, int B, int H, int W, void* stream) { return launch_sobel_bwd(g_b4hw, gx, B, H, W, S(stream)); }
+int sifsr_huber_partial_blocks(size_t n) { return huber_partial_blocks(n); }
+int sifsr_huber_fwd(const float* a, const float* b, float bscale, size_t n, float* partials, float* out, void* stream) {
+  return launch_huber_fwd(a, b, bscale, n, partials, out, S(stream));
+}
+int sifsr_huber_bwd(const float* a, const float* b, float bscale, const float* gout, size_t n, float* ga, void* stream) {
+  return launch_huber_bwd(a, b, bscale, gout, n, ga, S(stream));
+}
+size_t sifsr_sif_loss_workspace_bytes(int kind, int B, int H, int W) { return sif_loss_workspace_floats(kind, B, H, W) * sizeof(float); }
+int sifsr_sif_loss(int kind, const float* sr, const float* lst, const float* ndvi, int B, int H, int W, float mean, float std,
+                   float alpha, float gamma, const float* taps_ds9, const float* taps_ftm9, void* workspace,
+                   size_t workspace_bytes, float* losses3, float* dsr, void* stream) {
+  if (workspace_bytes < sifsr_sif_loss_workspace_bytes(kind, B, H, W)) return SIFSR_ERR_WORKSPACE;
+  return launch_sif_loss(kind, sr, lst, ndvi, B, H, W, mean, std, alpha, gamma, taps_ds9, taps_ftm9, (float*)workspace,
+                         losses3, dsr, S(stream));
+}
+
+int sifsr_adam_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  return launch_adam_flat(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S(stream));
+}

@@ -1,0 +1,71 @@
+// Shared declarations for the gfx950 (MI355X / CDNA4) SIF-CNN-SR kernels.
+//
+// Data layout: every activation *inside* the model is NHWC fp32
+// ([B][H][W][C], C in {16,32,64}); the model input (B,2,H,W) and output (B,1,H,W) keep the
+// reference's NCHW layout (model.py:608-645).  Parameters use the reference's own layouts
+// (conv OIHW, BN vectors) inside one flat fp32 buffer in `model.parameters()` order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SIFSR_OK 0
+#define SIFSR_ERR_SHAPE 1001      // unsupported / inconsistent shape
+#define SIFSR_ERR_ARG 1002        // null pointer, bad enum
+#define SIFSR_ERR_WORKSPACE 1003  // workspace too small
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define SIFSR_LAUNCH_CHECK()                         \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) return (int)e__;          \
+  } while (0)
+
+static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// relu(fma(v, scale, shift)) on 4 channels: BatchNorm (folded to scale/shift) + ReLU applied when a
+// consumer loads a raw conv output (model.py:136-137 / :139-140).
+static __device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh) {
+  float4 r;
+  r.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+  r.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+  r.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+  r.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Network table (mirrors oracle/sif_oracle.py CONV_BN_LAYERS == reference state_dict order)
+// ---------------------------------------------------------------------------------------------
+#define SIFSR_NUM_BN_LAYERS 17
+#define SIFSR_NUM_PARAMS 282705
+
+struct LayerInfo {
+  int cin, cout;
+  int level;       // 0: HxW, 1: /2, 2: /4, 3: /8
+  int w_off;       // offset of conv weight (OIHW) in the flat parameter buffer
+  int gamma_off;   // BN weight
+  int beta_off;    // BN bias
+  int run_off;     // offset in the flat running-stat buffer: [mean C][var C]
+  int ch_off;      // offset in per-channel scratch vectors (sum of cout of previous layers)
+  int wpack_off;   // offset in packed-weight buffers (fwd and dgrad share the offset table)
+};
+
+enum {
+  L_IN0 = 0, L_IN3, L_D1A, L_D1B, L_D1C, L_D2A, L_D2B, L_D2C, L_D3A, L_D3B, L_D3C,
+  L_U1A, L_U1B, L_U2A, L_U2B, L_U3A, L_U3B
+};
+
+struct NetTable {
+  LayerInfo L[SIFSR_NUM_BN_LAYERS];
+  int out_w_off, out_b_off;  // outlay weight (1,16,3,3) and bias
+  int total_params;          // 282705
+  int total_running;         // sum 2*cout
+  int total_channels;        // sum cout
+  int total_wpack;           // sum 9*cin*cout over MFMA layers (all but L_IN0)
+};
+
+const NetTable& sifsr_net();

@@ -1,0 +1,58 @@
+// Argument blocks of the 3x3 convolution kernels (internal; the C-ABI is include/sifsr_hip.h).
+#pragma once
+#include "common.h"
+
+// One input operand of a conv: channels [coff, coff + 16*nq) of an NHWC tensor with C channels.
+// scale/shift != nullptr: the tensor is a RAW conv output and relu(x*scale[c]+shift[c]) (the folded
+// BatchNorm + ReLU of the producing layer) is applied while staging; nullptr: used as stored.
+struct ConvSrc {
+  const float* ptr;
+  const float* scale;
+  const float* shift;
+  int C;
+  int coff;
+  int nq;   // number of 16-channel blocks taken from this operand
+};
+
+struct ConvDst {
+  float* ptr;
+  int C;
+  int coff;
+};
+
+struct ConvArgs {
+  ConvSrc src[2];       // channel concat [src0 | src1] (torch.cat([up, skip], 1), model.py:247)
+  ConvDst dst[2];       // output channel blocks [0, dst_split) -> dst[0], the rest -> dst[1]
+  const float* wpack;   // fragment-ordered weights, see pack_weights_kernel
+  const float* addend;  // optional tensor added to dst[0] in the epilogue (residual gradient), C = addC
+  float* stat_partials; // optional [grid blocks][Cout][2] per-block (sum, sum of squares) of the output
+  int addC;
+  int dst_split;        // in 16-channel blocks
+  int B, H, W;
+  int NQ;               // 16-channel blocks of the contraction (Cin / 16)
+};
+
+// conv3x3, stride 1, NHWC fp32, MFMA implicit GEMM.  zero_pad = 0: replicate padding (forward,
+// nn.Conv2d(padding_mode='replicate'), model.py:135); zero_pad = 1: zero padding (the interior part
+// of the transposed conv used by dgrad; the replicate-border fold is dgrad_border_fix).
+int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s);
+
+struct WgradArgs {
+  ConvSrc src[2];      // the conv's forward input (same description as in the forward call)
+  const float* dy;     // gradient w.r.t. the raw conv output, NHWC, Cout channels
+  float* slabs;        // [nblk][chunks][9*cin_chunk*Cout] per-block partial dW in fragment order
+  int B, H, W;
+  int NQ;              // Cin / 16 (total)
+  int ntiles;          // B * (H/8) * (W/16)
+};
+// returns the number of slab blocks used through *nblk_out
+int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s);
+int launch_wgrad_reduce(const float* slabs, int nblk, int cin, int cout, float* dw_oihw, hipStream_t s);
+size_t wgrad_slab_floats(int cin, int cout);   // floats per block
+
+// dgrad: replicate-padding adjoint fold for the border pixels (adds to g_in).
+int launch_dgrad_border_fix(const float* dy, int Cout, const float* w_oihw, int Cin,
+                            float* g0, int C0, int coff0, int split_ch, float* g1, int C1, int coff1,
+                            int B, int H, int W, hipStream_t s);
+
+int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStream_t s);

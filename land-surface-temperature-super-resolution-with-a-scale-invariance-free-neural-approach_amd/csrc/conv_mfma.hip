@@ -1,0 +1,339 @@
+// 3x3 convolution (stride 1) as an implicit GEMM on the fp32 matrix cores of gfx950.
+//
+// Replaces what the reference dispatches to ATen/MKLDNN/cuDNN for nn.Conv2d(k=3, padding=1,
+// padding_mode='replicate', bias=False) -- model.py:135,138,507 -- and its input-gradient.
+//
+// Mapping (one workgroup = 256 threads = 4 waves, one 16x16-pixel output tile of one image):
+//   * the (16+2)x(16+2) input halo tile of one 16-channel block is staged in LDS as
+//     [channel-quad k][pixel][4 channels]  (plane stride 336 pixels = 0 mod 16 slots), with the
+//     producing layer's BatchNorm+ReLU folded into the staging (relu(x*scale+shift));
+//   * v_mfma_f32_16x16x4_f32: A = weights (16 cout x 4 cin), B = activations (4 cin x 16 pixels of
+//     one image row), D = 16 cout x 16 pixels.  Lane (i = lane&15, k = lane>>4) reads ONE
+//     ds_read_b128 = channels 4k..4k+3 of pixel i and feeds 4 MFMAs (k-step j uses channel 4k+j on
+//     both operands -- the contraction order inside a 16-channel block is a free permutation);
+//     this read is bank-conflict free;
+//   * weights come pre-packed in fragment order (pack_weights_kernel): one coalesced
+//     global_load_dwordx4 per (cout block, cin block, tap) per wave, L2 resident;
+//   * D rows are 4 consecutive cout per lane -> one 16-byte NHWC store per lane per tile row;
+//   * optional epilogue: per-channel (sum, sumsq) of the tile for training-mode BatchNorm statistics,
+//     reduced with wave shuffles + LDS and written per workgroup (deterministic 2-stage reduction).
+#include "conv.h"
+
+namespace {
+
+constexpr int PW = 18;        // plane width  (16 + 2 halo)
+constexpr int PLANE = 336;    // 18*18 = 324 pixels, padded to a multiple of 16 (bank rule)
+
+template <int NB, bool ZERO_PAD>
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
+  constexpr int CBW = NB >= 4 ? NB / 4 : 1;                 // cout blocks per wave
+  constexpr int NG = NB == 1 ? 4 : (NB == 2 ? 8 : 16);      // tile rows per wave
+
+  __shared__ float4 lds[4 * PLANE];
+  __shared__ float red[4][CBW][16][2];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16, b = blockIdx.z;
+  const int H = a.H, W = a.W;
+
+  const int nb0 = NB == 1 ? 0 : (NB == 2 ? (wave & 1) : wave);
+  const int g0 = NB == 1 ? wave * 4 : (NB == 2 ? (wave >> 1) * 8 : 0);
+
+  f32x4 acc[CBW][NG];
+#pragma unroll
+  for (int c = 0; c < CBW; ++c)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[c][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging map: thread -> (channel quad cg, 6 halo pixels) ----
+  const int cg = tid & 3;
+  const int pslot = tid >> 2;
+  int poff[6];
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int p = pslot + 64 * it;
+    const int py = p / PW, px = p - py * PW;
+    int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    bool ok = p < PW * PW;
+    if (ZERO_PAD) {
+      ok = ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    } else {
+      gy = clampi(gy, 0, H - 1);
+      gx = clampi(gx, 0, W - 1);
+    }
+    poff[it] = ok ? (b * H + gy) * W + gx : -1;
+  }
+
+  float4 stg[6];
+  auto issue_loads = [&](int q) {
+    const bool first = q < a.src[0].nq;
+    const ConvSrc& s = first ? a.src[0] : a.src[1];
+    const int ch = s.coff + 16 * (first ? q : q - a.src[0].nq) + 4 * cg;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      stg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (poff[it] >= 0) stg[it] = ld4(s.ptr + (size_t)poff[it] * s.C + ch);
+    }
+    if (s.scale != nullptr) {
+      const float4 sc = ld4(s.scale + ch), sh = ld4(s.shift + ch);
+#pragma unroll
+      for (int it = 0; it < 6; ++it)
+        if (poff[it] >= 0) stg[it] = bn_relu4(stg[it], sc, sh);
+    }
+  };
+
+  const int NQ = a.NQ;
+  issue_loads(0);
+
+  for (int q = 0; q < NQ; ++q) {
+    // weights of this 16-channel block for my cout block(s): 9 taps x float4 (4 k-steps)
+    float4 wf[CBW][9];
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) {
+      const int nb = nb0 + 4 * c;
+      const float* wp = a.wpack + ((size_t)(nb * NQ + q) * 9) * 256 + lane * 4;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wf[c][t] = ld4(wp + t * 256);
+    }
+
+    __syncthreads();   // every wave is done reading the previous block's tile
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int p = pslot + 64 * it;
+      if (p < PW * PW) lds[cg * PLANE + p] = stg[it];
+    }
+    __syncthreads();
+    if (q + 1 < NQ) issue_loads(q + 1);   // in flight while this block is multiplied
+
+    const int kq = lane >> 4, px = lane & 15;
+#pragma unroll
+    for (int gb = 0; gb < NG / 4; ++gb) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ty = t / 3, tx = t - 3 * (t / 3);
+        float4 bf[4];
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+          const int r = g0 + gb * 4 + gi;
+          bf[gi] = lds[kq * PLANE + (r + ty) * PW + tx + px];
+        }
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) {
+          const float4 w = wf[c][t];
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi)
+            acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, bf[gi].x, acc[c][gb * 4 + gi], 0, 0, 0);
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi)
+            acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, bf[gi].y, acc[c][gb * 4 + gi], 0, 0, 0);
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi)
+            acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, bf[gi].z, acc[c][gb * 4 + gi], 0, 0, 0);
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi)
+            acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, bf[gi].w, acc[c][gb * 4 + gi], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: NHWC stores (+ residual addend) and per-channel statistics ----
+  const int kq = lane >> 4, px = lane & 15;
+  float s1[CBW][4], s2[CBW][4];
+#pragma unroll
+  for (int c = 0; c < CBW; ++c) {
+    const int nb = nb0 + 4 * c;
+    const bool d0 = nb < a.dst_split;
+    const ConvDst& d = d0 ? a.dst[0] : a.dst[1];
+    const int ch = d.coff + 16 * (d0 ? nb : nb - a.dst_split) + 4 * kq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[c][r] = s2[c][r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const size_t pix = (size_t)(b * H + y0 + g0 + g) * W + x0 + px;
+      f32x4 v = acc[c][g];
+      if (a.addend != nullptr) {
+        const float4 ad = ld4(a.addend + pix * a.addC + 16 * nb + 4 * kq);
+        v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+      }
+      st4(d.ptr + pix * d.C + ch, make_float4(v[0], v[1], v[2], v[3]));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[c][r] += v[r]; s2[c][r] = fmaf(v[r], v[r], s2[c][r]); }
+    }
+  }
+
+  if (a.stat_partials != nullptr) {
+#pragma unroll
+    for (int c = 0; c < CBW; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float u = s1[c][r], v = s2[c][r];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
+        if (px == 0) { red[wave][c][4 * kq + r][0] = u; red[wave][c][4 * kq + r][1] = v; }
+      }
+    __syncthreads();
+    if (tid < NB * 16) {
+      const int nb = tid >> 4, cc = tid & 15;
+      float u = 0.f, v = 0.f;
+      if (NB == 1) {
+        for (int w = 0; w < 4; ++w) { u += red[w][0][cc][0]; v += red[w][0][cc][1]; }
+      } else if (NB == 2) {
+        for (int w = nb; w < 4; w += 2) { u += red[w][0][cc][0]; v += red[w][0][cc][1]; }
+      } else {
+        u = red[nb & 3][nb >> 2][cc][0]; v = red[nb & 3][nb >> 2][cc][1];
+      }
+      const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      float* o = a.stat_partials + (blk * (NB * 16) + tid) * 2;
+      o[0] = u; o[1] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: OIHW parameters -> MFMA fragment order, for forward and for dgrad
+//   fwd  : wf[nb][q][tap][lane][j] = W[co = 16nb + (lane&15)][ci = 16q + 4(lane>>4) + j][tap]
+//   dgrad: wd[nb][q][tap][lane][j] = W[co = 16q + 4(lane>>4) + j][ci = 16nb + (lane&15)][8 - tap]
+//          (transposed and spatially flipped: dx[p] = sum_t W_t^T dy[p - t])
+// ---------------------------------------------------------------------------------------------
+struct PackTable { int w_off[16], cin[16], cout[16], p_off[16]; };
+
+__global__ void pack_weights_kernel(const float* __restrict__ params, float* __restrict__ wfwd,
+                                    float* __restrict__ wdg, const PackTable tb) {
+  const int l = blockIdx.y;
+  const int cin = tb.cin[l], cout = tb.cout[l];
+  const int n = 9 * cin * cout;
+  const float* W = params + tb.w_off[l];
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int j = e & 3, lane = (e >> 2) & 63;
+    const int rest = e >> 8;
+    const int tap = rest % 9, r2 = rest / 9;
+    {
+      const int NQ = cin / 16;
+      const int q = r2 % NQ, nb = r2 / NQ;
+      const int co = 16 * nb + (lane & 15), ci = 16 * q + 4 * (lane >> 4) + j;
+      wfwd[tb.p_off[l] + e] = W[(co * cin + ci) * 9 + tap];
+    }
+    {
+      const int NQ = cout / 16;
+      const int q = r2 % NQ, nb = r2 / NQ;
+      const int co = 16 * q + 4 * (lane >> 4) + j, ci = 16 * nb + (lane & 15);
+      wdg[tb.p_off[l] + e] = W[(co * cin + ci) * 9 + (8 - tap)];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dgrad border fold.  Forward reads x[clamp(p + t)] (replicate padding); its adjoint sends the
+// gradient of every out-of-range read back to the clamped pixel:
+//   g[q] = sum_t W_t^T * sum_{p : clamp(p+t) = q} dy[p]
+// The MFMA kernel (zero_pad) already added the p = q - t terms; this kernel adds the rest, which is
+// non-empty only for q on the image border.  Per axis the extra source exists only for
+// (q = 0, t = -1) -> p = 0 and (q = N-1, t = +1) -> p = N-1.
+// One thread per (border pixel, input channel).
+// ---------------------------------------------------------------------------------------------
+__global__ void dgrad_border_fix_kernel(const float* __restrict__ dy, int Cout, const float* __restrict__ Wt,
+                                        int Cin, float* g0, int C0, int coff0, int split_ch, float* g1,
+                                        int C1, int coff1, int B, int H, int W) {
+  const int per_img = 2 * W + 2 * (H - 2);
+  const int total = B * per_img * Cin;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int ci = e % Cin;
+    const int bp = (e / Cin) % per_img;
+    const int b = e / (Cin * per_img);
+    int qy, qx;
+    if (bp < W) { qy = 0; qx = bp; }
+    else if (bp < 2 * W) { qy = H - 1; qx = bp - W; }
+    else { const int r = bp - 2 * W; qy = 1 + (r >> 1); qx = (r & 1) ? W - 1 : 0; }
+    float acc = 0.f;
+    for (int ty = -1; ty <= 1; ++ty) {
+      // candidate source rows for this tap: base (qy - ty) and the clamped extra
+      int ys[2], ny = 0; bool ybase[2];
+      if (qy - ty >= 0 && qy - ty < H) { ys[ny] = qy - ty; ybase[ny++] = true; }
+      if ((qy == 0 && ty == -1) || (qy == H - 1 && ty == 1)) { ys[ny] = qy; ybase[ny++] = false; }
+      for (int tx = -1; tx <= 1; ++tx) {
+        int xs[2], nx = 0; bool xbase[2];
+        if (qx - tx >= 0 && qx - tx < W) { xs[nx] = qx - tx; xbase[nx++] = true; }
+        if ((qx == 0 && tx == -1) || (qx == W - 1 && tx == 1)) { xs[nx] = qx; xbase[nx++] = false; }
+        const int tap = (ty + 1) * 3 + (tx + 1);
+        for (int iy = 0; iy < ny; ++iy)
+          for (int ix = 0; ix < nx; ++ix) {
+            if (ybase[iy] && xbase[ix]) continue;   // already done by the MFMA kernel
+            const float* d = dy + ((size_t)(b * H + ys[iy]) * W + xs[ix]) * Cout;
+            float s = 0.f;
+            for (int co = 0; co < Cout; ++co) s = fmaf(Wt[(co * Cin + ci) * 9 + tap], d[co], s);
+            acc += s;
+          }
+      }
+    }
+    const size_t pix = (size_t)(b * H + qy) * W + qx;
+    if (ci < split_ch) g0[pix * C0 + coff0 + ci] += acc;
+    else g1[pix * C1 + coff1 + ci - split_ch] += acc;
+  }
+}
+
+}  // namespace
+
+int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s) {
+  if (a.H % 16 || a.W % 16 || cout % 16 || a.NQ < 1 || a.src[0].nq + a.src[1].nq != a.NQ) return SIFSR_ERR_SHAPE;
+  if (!a.src[0].ptr || !a.dst[0].ptr || !a.wpack) return SIFSR_ERR_ARG;
+  const dim3 grid(a.W / 16, a.H / 16, a.B), block(256);
+  const int nb = cout / 16;
+#define SIFSR_CONV_CASE(NBV)                                                                      \
+  case NBV:                                                                                       \
+    if (zero_pad) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, true>), grid, block, 0, s, a);     \
+    else hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, false>), grid, block, 0, s, a);             \
+    break;
+  switch (nb) {
+    SIFSR_CONV_CASE(1)
+    SIFSR_CONV_CASE(2)
+    SIFSR_CONV_CASE(4)
+    SIFSR_CONV_CASE(8)
+    default: return SIFSR_ERR_SHAPE;
+  }
+#undef SIFSR_CONV_CASE
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStream_t s) {
+  const NetTable& nt = sifsr_net();
+  PackTable tb;
+  int maxn = 0;
+  for (int l = 1; l < SIFSR_NUM_BN_LAYERS; ++l) {
+    tb.w_off[l - 1] = nt.L[l].w_off;
+    tb.cin[l - 1] = nt.L[l].cin;
+    tb.cout[l - 1] = nt.L[l].cout;
+    tb.p_off[l - 1] = nt.L[l].wpack_off;
+    const int n = 9 * nt.L[l].cin * nt.L[l].cout;
+    maxn = n > maxn ? n : maxn;
+  }
+  const dim3 grid((maxn + 255) / 256 > 64 ? 64 : (maxn + 255) / 256, 16);
+  hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, s, params, wfwd, wdgrad, tb);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_pack_weights_one(const float* w, int cin, int cout, float* wfwd, float* wdg, hipStream_t s) {
+  PackTable tb;
+  tb.w_off[0] = 0; tb.cin[0] = cin; tb.cout[0] = cout; tb.p_off[0] = 0;
+  const int n = 9 * cin * cout;
+  const dim3 grid((n + 255) / 256 > 64 ? 64 : (n + 255) / 256, 1);
+  hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, s, w, wfwd, wdg, tb);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_dgrad_border_fix(const float* dy, int Cout, const float* w_oihw, int Cin, float* g0, int C0,
+                            int coff0, int split_ch, float* g1, int C1, int coff1, int B, int H, int W,
+                            hipStream_t s) {
+  const int total = B * (2 * W + 2 * (H - 2)) * Cin;
+  int blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dgrad_border_fix_kernel, dim3(blocks), dim3(256), 0, s, dy, Cout, w_oihw, Cin, g0, C0,
+                     coff0, split_ch, g1, C1, coff1, B, H, W);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}

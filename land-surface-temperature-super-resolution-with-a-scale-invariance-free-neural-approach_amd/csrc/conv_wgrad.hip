@@ -1,0 +1,196 @@
+// Weight gradient of the replicate-padded 3x3 convolution on the fp32 matrix cores:
+//   dW[co][ci][t] = sum_{b,y,x} dy[b,y,x,co] * a_in[b, clamp(y+ty), clamp(x+tx), ci]
+// (the reduction ATen/cuDNN performs for nn.Conv2d backward-weight, model.py:135,138,507).
+//
+// GEMM view per tap: dW_t (Cout x Cin) = dY^T (Cout x P) * A_t (P x Cin), P = B*H*W pixels.
+// v_mfma_f32_16x16x4_f32 with the 4-deep K index = 4 consecutive pixels of a row:
+//   A operand: lane (i = co, k = pixel)  <- dy   tile  in LDS  [pixel][Cout + pad]
+//   B operand: lane (j = ci, k = pixel)  <- a_in halo tile in LDS [pixel][Cin + pad], shifted by tap
+// Row strides are = 16 (mod 32) floats so both ds_read_b32 patterns are bank-conflict free.
+// A workgroup walks 8x16-pixel tiles (persistent grid), keeps its dW partial in MFMA accumulators,
+// and writes ONE slab per workgroup; wgrad_reduce_kernel sums the slabs in a fixed order
+// (deterministic, no float atomics) and scatters to the OIHW gradient.
+#include "conv.h"
+
+namespace {
+
+constexpr int WT_ROWS = 8;                 // tile rows
+constexpr int WPW = 18, WPH = WT_ROWS + 2; // halo tile
+constexpr int WPIX_IN = WPW * WPH;         // 180
+constexpr int WPIX_OUT = 16 * WT_ROWS;     // 128
+
+template <int NBO, int NBI>   // cout blocks, cin blocks handled by one workgroup (cin chunk = blockIdx.y)
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
+  constexpr int WO = NBO >= 2 ? 2 : 1, WI = NBI >= 2 ? 2 : 1, WP = 4 / (WO * WI);
+  constexpr int NBO_W = NBO / WO, NBI_W = NBI / WI;
+  constexpr int CSO = NBO * 16 + (NBO % 2 == 0 ? 16 : 0);   // = 16 mod 32
+  constexpr int CSI = NBI * 16 + (NBI % 2 == 0 ? 16 : 0);
+  constexpr int NT = NBO_W * NBI_W * 9;                       // accumulator tiles per wave
+
+  __shared__ float smem[WPIX_OUT * CSO + WPIX_IN * CSI];
+  float* const lds_dy = smem;
+  float* const lds_in = smem + WPIX_OUT * CSO;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wo = wave % WO, wi = (wave / WO) % WI, wp = wave / (WO * WI);
+  const int H = a.H, W = a.W;
+  const int tiles_x = W / 16, tiles_y = H / WT_ROWS;
+  const int q0 = blockIdx.y * NBI;   // first 16-channel block of my cin chunk
+  const int Cout = NBO * 16;
+
+  f32x4 acc[NBO_W][NBI_W][9];
+#pragma unroll
+  for (int o = 0; o < NBO_W; ++o)
+#pragma unroll
+    for (int i = 0; i < NBI_W; ++i)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[o][i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int x0 = tx * 16, y0 = ty * WT_ROWS;
+    __syncthreads();
+    // ---- stage dy tile: 128 pixels x Cout, float4 granules ----
+    for (int e = tid; e < WPIX_OUT * (Cout / 4); e += 256) {
+      const int c4 = e % (Cout / 4), p = e / (Cout / 4);
+      const int py = p >> 4, px = p & 15;
+      const float4 v = ld4(a.dy + ((size_t)(b * H + y0 + py) * W + x0 + px) * Cout + 4 * c4);
+      *reinterpret_cast<float4*>(&lds_dy[p * CSO + 4 * c4]) = v;
+    }
+    // ---- stage a_in halo tile (replicate clamp) with the producer's BN+ReLU folded in ----
+    for (int e = tid; e < WPIX_IN * (NBI * 4); e += 256) {
+      const int c4 = e % (NBI * 4), p = e / (NBI * 4);
+      const int py = p / WPW, px = p - py * WPW;
+      const int gy = clampi(y0 - 1 + py, 0, H - 1), gx = clampi(x0 - 1 + px, 0, W - 1);
+      const int q = q0 + (c4 >> 2);
+      const bool first = q < a.src[0].nq;
+      const ConvSrc& s = first ? a.src[0] : a.src[1];
+      const int ch = s.coff + 16 * (first ? q : q - a.src[0].nq) + 4 * (c4 & 3);
+      float4 v = ld4(s.ptr + ((size_t)(b * H + gy) * W + gx) * s.C + ch);
+      if (s.scale != nullptr) v = bn_relu4(v, ld4(s.scale + ch), ld4(s.shift + ch));
+      *reinterpret_cast<float4*>(&lds_in[p * CSI + 4 * c4]) = v;
+    }
+    __syncthreads();
+
+    const int i16 = lane & 15, k = lane >> 4;
+    // k-steps: (row r, pixel quad qd); this wave takes every WP-th one
+    for (int ks = wp; ks < WT_ROWS * 4; ks += WP) {
+      const int r = ks >> 2, qd = ks & 3;
+      float av[NBO_W];
+#pragma unroll
+      for (int o = 0; o < NBO_W; ++o)
+        av[o] = lds_dy[(r * 16 + 4 * qd + k) * CSO + 16 * (wo * NBO_W + o) + i16];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int tyy = t / 3, txx = t - 3 * (t / 3);
+        float bv[NBI_W];
+#pragma unroll
+        for (int i = 0; i < NBI_W; ++i)
+          bv[i] = lds_in[((r + tyy) * WPW + 4 * qd + k + txx) * CSI + 16 * (wi * NBI_W + i) + i16];
+#pragma unroll
+        for (int o = 0; o < NBO_W; ++o)
+#pragma unroll
+          for (int i = 0; i < NBI_W; ++i)
+            acc[o][i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[o], bv[i], acc[o][i][t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- combine the WP pixel-split waves through LDS, then write the slab ----
+  // slab layout (floats): [chunk][nbo][nbi][tap][lane][4]
+  const size_t slab_floats = (size_t)gridDim.y * NBO * NBI * 9 * 256;
+  float* slab = a.slabs + (size_t)blockIdx.x * slab_floats + (size_t)blockIdx.y * NBO * NBI * 9 * 256;
+  if (WP > 1) {
+    // one round per extra pixel-split wave group: it parks its tiles in LDS, group 0 adds them
+    static_assert(WP == 1 || WO * WI * NT * 256 <= WPIX_OUT * CSO + WPIX_IN * CSI, "wgrad reduction scratch too small");
+    float* const mine = smem + ((size_t)(wi * WO + wo) * NT) * 256;
+    for (int w = 1; w < WP; ++w) {
+      __syncthreads();
+      if (wp == w) {
+#pragma unroll
+        for (int o = 0; o < NBO_W; ++o)
+#pragma unroll
+          for (int i = 0; i < NBI_W; ++i)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+              const f32x4 v = acc[o][i][t];
+              *reinterpret_cast<float4*>(mine + ((o * NBI_W + i) * 9 + t) * 256 + lane * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+      }
+      __syncthreads();
+      if (wp == 0) {
+#pragma unroll
+        for (int o = 0; o < NBO_W; ++o)
+#pragma unroll
+          for (int i = 0; i < NBI_W; ++i)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+              const float4 v = *reinterpret_cast<const float4*>(mine + ((o * NBI_W + i) * 9 + t) * 256 + lane * 4);
+              acc[o][i][t][0] += v.x; acc[o][i][t][1] += v.y; acc[o][i][t][2] += v.z; acc[o][i][t][3] += v.w;
+            }
+      }
+    }
+  }
+  if (wp == 0) {
+#pragma unroll
+    for (int o = 0; o < NBO_W; ++o)
+#pragma unroll
+      for (int i = 0; i < NBI_W; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int nbo = wo * NBO_W + o, nbi = wi * NBI_W + i;
+          const f32x4 v = acc[o][i][t];
+          st4(slab + ((size_t)((nbo * NBI + nbi) * 9 + t)) * 256 + lane * 4, make_float4(v[0], v[1], v[2], v[3]));
+        }
+  }
+}
+
+// dW[co][ci][t] = sum over workgroups of slab[blk][chunk][nbo][nbi][t][lane][r]
+//   co = 16 nbo + 4 (lane>>4) + r,  ci = 16 (chunk*NBI + nbi) + (lane & 15)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int nblk, int cin, int cout, int nbi_chunk,
+                                    float* __restrict__ dw) {
+  const int n = 9 * cin * cout;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int t = e % 9, ci = (e / 9) % cin, co = e / (9 * cin);
+  const int nbo = co >> 4, lane = ((co & 15) >> 2) * 16 + (ci & 15), r = co & 3;
+  const int qi = ci >> 4, chunk = qi / nbi_chunk, nbi = qi % nbi_chunk;
+  const int NBO = cout / 16;
+  const size_t per_chunk = (size_t)NBO * nbi_chunk * 9 * 256;
+  const size_t slab_floats = (size_t)n;   // == chunks * per_chunk
+  const float* p = slabs + chunk * per_chunk + ((size_t)((nbo * nbi_chunk + nbi) * 9 + t)) * 256 + lane * 4 + r;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += (double)p[(size_t)k * slab_floats];
+  dw[e] = (float)s;
+}
+
+template <int NBO, int NBI>
+int launch_wgrad_t(const WgradArgs& a, int chunks, int nblk, hipStream_t s) {
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<NBO, NBI>), dim3(nblk, chunks), dim3(256), 0, s, a);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+}  // namespace
+
+size_t wgrad_slab_floats(int cin, int cout) { return (size_t)9 * cin * cout; }
+
+static int wgrad_nbi_chunk(int cin) { return cin > 64 ? 4 : cin / 16; }
+
+int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s) {
+  if (a.H % WT_ROWS || a.W % 16 || cin % 16 || cout % 16 || nblk < 1) return SIFSR_ERR_SHAPE;
+  const int nbi = wgrad_nbi_chunk(cin), chunks = (cin / 16) / nbi, nbo = cout / 16;
+#define SIFSR_WG(NBOV, NBIV) if (nbo == NBOV && nbi == NBIV) return launch_wgrad_t<NBOV, NBIV>(a, chunks, nblk, s);
+  SIFSR_WG(1, 1) SIFSR_WG(1, 2) SIFSR_WG(2, 1) SIFSR_WG(2, 2) SIFSR_WG(4, 2) SIFSR_WG(2, 4) SIFSR_WG(4, 4)
+#undef SIFSR_WG
+  return SIFSR_ERR_SHAPE;
+}
+
+int launch_wgrad_reduce(const float* slabs, int nblk, int cin, int cout, float* dw_oihw, hipStream_t s) {
+  const int n = 9 * cin * cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, slabs, nblk, cin, cout,
+                     wgrad_nbi_chunk(cin), dw_oihw);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}

@@ -1,0 +1,40 @@
+// Launchers of the VALU edge convolutions, BatchNorm, resampling, loss and optimizer kernels
+// (internal; the C-ABI is include/sifsr_hip.h).
+#pragma once
+#include "common.h"
+
+// ---- edge_conv.hip ----
+int launch_conv_in_fwd(const float* x, const float* w, float* y, float* partials, int B, int H, int W, hipStream_t s);
+int launch_conv_in_wgrad(const float* x, const float* dy, float* partials, int nblk, float* dw, int B, int H, int W, hipStream_t s);
+int launch_conv_out_fwd(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
+                        float* out, int B, int H, int W, hipStream_t s);
+int launch_conv_out_dgrad(const float* dsr, const float* w, float* g, int B, int H, int W, hipStream_t s);
+int launch_conv_out_wgrad(const float* y, const float* scale, const float* shift, const float* dsr, float* partials,
+                          int nblk, float* dw, float* db, int B, int H, int W, hipStream_t s);
+int launch_sum_partials(const float* partials, int nblk, int n, float* out, hipStream_t s);
+
+// ---- bn.hip ----
+// training: per-workgroup (sum, sumsq) partials -> batch mean / invstd, folded scale/shift, running-stat update
+int launch_bn_finalize(const float* partials, int nblk, int C, double count, const float* gamma, const float* beta,
+                       float* run_mean, float* run_var, float momentum, float eps, float* mean, float* invstd,
+                       float* scale, float* shift, hipStream_t s);
+// eval: scale/shift from the running statistics of all 17 layers in one launch
+int launch_bn_eval_coeffs(const float* params, const float* running, float eps, float* scale, float* shift, hipStream_t s);
+int launch_bn_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, int C, size_t npix, float* partials, int nblk, hipStream_t s);
+int launch_bn_bwd_finalize(const float* partials, int nblk, int C, double count, const float* scale, const float* mean,
+                           const float* invstd, float* dgamma, float* dbeta, float* c1, float* c0, hipStream_t s);
+int launch_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, const float* c1,
+                        const float* c0, int C, size_t npix, float* dy, hipStream_t s);
+int launch_nbt_increment(long long* nbt, int n, hipStream_t s);
+
+// ---- resample.hip ---- (all NHWC, C % 4 == 0; scale == nullptr => input used as stored)
+int launch_bnrelu_pool2(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W, int C, hipStream_t s);
+int launch_bnrelu_add(const float* p, const float* y, const float* scale, const float* shift, float* out, int C, size_t npix, hipStream_t s);
+int launch_bnrelu_up2x(const float* y, const float* scale, const float* shift, float* out, int B, int Hin, int Win, int C, hipStream_t s);
+int launch_pool2_bwd(const float* gp, float* g, int B, int H, int W, int C, int accumulate, hipStream_t s);
+int launch_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, hipStream_t s);
+
+// ---- adam.hip ----
+int launch_adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, float grad_scale, hipStream_t s);

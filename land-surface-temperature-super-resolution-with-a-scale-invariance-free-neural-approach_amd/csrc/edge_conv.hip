@@ -1,0 +1,271 @@
+// The two convolutions that are too thin for the matrix cores:
+//   * inbloc.bloc.0 : Conv2d(2 -> 16), reads the model's NCHW input (model.py:596, :135)   K = 18
+//   * outlay        : Conv2d(16 -> 1) + bias, writes the NCHW output (model.py:605)        N = 1
+// Both are plain VALU FMA kernels over 16x16-pixel tiles staged in LDS; replicate padding.
+#include "edge_conv.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// input conv forward: x (B,2,H,W) NCHW -> y (B,H,W,16) NHWC raw, + BatchNorm partial statistics
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ y, float* __restrict__ partials,
+                                                          int H, int W) {
+  __shared__ float tile[2][18 * 18];
+  __shared__ float red[4][16][2];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16, b = blockIdx.z;
+  for (int e = tid; e < 2 * 324; e += 256) {
+    const int c = e / 324, p = e - c * 324;
+    const int py = p / 18, px = p - py * 18;
+    const int gy = clampi(y0 - 1 + py, 0, H - 1), gx = clampi(x0 - 1 + px, 0, W - 1);
+    tile[c][p] = x[((size_t)(b * 2 + c) * H + gy) * W + gx];
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  float in[18];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) in[c * 9 + t] = tile[c][(ty + t / 3) * 18 + tx + t % 3];
+  float o[16];
+#pragma unroll
+  for (int co = 0; co < 16; ++co) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) s = fmaf(w[co * 18 + k], in[k], s);   // w is OIHW: [co][ci][t]
+    o[co] = s;
+  }
+  float* yp = y + ((size_t)(b * H + y0 + ty) * W + x0 + tx) * 16;
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) st4(yp + 4 * c4, make_float4(o[4 * c4], o[4 * c4 + 1], o[4 * c4 + 2], o[4 * c4 + 3]));
+
+  if (partials != nullptr) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int co = 0; co < 16; ++co) {
+      float u = o[co], v = o[co] * o[co];
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
+      if (lane == 0) { red[wave][co][0] = u; red[wave][co][1] = v; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int co = tid >> 1, j = tid & 1;
+      const float s = red[0][co][j] + red[1][co][j] + red[2][co][j] + red[3][co][j];
+      const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      partials[(blk * 16 + co) * 2 + j] = s;
+    }
+  }
+}
+
+// input conv weight gradient: dW[co][ci][t] = sum dy[p][co] * x[clamp(p+t)][ci]; 288 outputs.
+// persistent workgroups, per-workgroup partial [288], summed by sum_partials_kernel.
+__global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ partials, int B, int H, int W) {
+  __shared__ float tile[2][18 * 18];
+  __shared__ float dyt[256 * 16];
+  const int tid = threadIdx.x;
+  const int tiles_x = W / 16, tiles_y = H / 16, ntiles = B * tiles_x * tiles_y;
+  // thread -> outputs e0 = tid and e1 = tid + 256 (< 288); e = co*18 + ci*9 + t
+  const int e0 = tid, e1 = tid + 256;
+  const bool has1 = e1 < 288;
+  const int co0 = e0 / 18, k0 = e0 % 18, co1 = has1 ? e1 / 18 : 0, k1 = has1 ? e1 % 18 : 0;
+  const int off0 = (k0 % 9) / 3 * 18 + (k0 % 9) % 3, off1 = (k1 % 9) / 3 * 18 + (k1 % 9) % 3;
+  const float* t0 = tile[k0 / 9];
+  const float* t1 = tile[k1 / 9];
+  float a0 = 0.f, a1 = 0.f;
+  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, b = tl / (tiles_x * tiles_y);
+    const int x0 = tx * 16, y0 = ty * 16;
+    __syncthreads();
+    for (int e = tid; e < 2 * 324; e += 256) {
+      const int c = e / 324, p = e - c * 324;
+      const int py = p / 18, px = p - py * 18;
+      const int gy = clampi(y0 - 1 + py, 0, H - 1), gx = clampi(x0 - 1 + px, 0, W - 1);
+      tile[c][p] = x[((size_t)(b * 2 + c) * H + gy) * W + gx];
+    }
+    for (int e = tid; e < 256 * 4; e += 256) {
+      const int p = e >> 2, c4 = e & 3;
+      *reinterpret_cast<float4*>(&dyt[p * 16 + 4 * c4]) =
+          ld4(dy + ((size_t)(b * H + y0 + (p >> 4)) * W + x0 + (p & 15)) * 16 + 4 * c4);
+    }
+    __syncthreads();
+    for (int p = 0; p < 256; ++p) {
+      const int base = (p >> 4) * 18 + (p & 15);
+      a0 = fmaf(dyt[p * 16 + co0], t0[base + off0], a0);
+      if (has1) a1 = fmaf(dyt[p * 16 + co1], t1[base + off1], a1);
+    }
+  }
+  partials[(size_t)blockIdx.x * 288 + e0] = a0;
+  if (has1) partials[(size_t)blockIdx.x * 288 + e1] = a1;
+}
+
+// ------------------------------------------------------------------------------------------
+// output conv forward: a = relu(y*scale+shift) (B,H,W,16) -> sr (B,1,H,W) = conv(a) + bias
+// ------------------------------------------------------------------------------------------
+constexpr int OCS = 20;   // LDS pixel stride (floats): 5 slots of 16 B -> conflict-free b128 reads
+
+__device__ __forceinline__ void stage_out_tile(float* tile, const float* __restrict__ y, const float* scale,
+                                               const float* shift, int b, int y0, int x0, int H, int W, int tid) {
+  for (int e = tid; e < 324 * 4; e += 256) {
+    const int p = e >> 2, c4 = e & 3;
+    const int py = p / 18, px = p - py * 18;
+    const int gy = clampi(y0 - 1 + py, 0, H - 1), gx = clampi(x0 - 1 + px, 0, W - 1);
+    float4 v = ld4(y + ((size_t)(b * H + gy) * W + gx) * 16 + 4 * c4);
+    if (scale != nullptr) v = bn_relu4(v, ld4(scale + 4 * c4), ld4(shift + 4 * c4));
+    *reinterpret_cast<float4*>(&tile[p * OCS + 4 * c4]) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_out_fwd_kernel(const float* __restrict__ y, const float* scale,
+                                                           const float* shift, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int H, int W) {
+  __shared__ float tile[324 * OCS];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16, b = blockIdx.z;
+  stage_out_tile(tile, y, scale, shift, b, y0, x0, H, W, tid);
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  float s = bias[0];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float* p = &tile[((ty + t / 3) * 18 + tx + t % 3) * OCS];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + 4 * c4);
+      s = fmaf(w[(4 * c4 + 0) * 9 + t], v.x, s);   // w is (1,16,3,3): [ci][t]
+      s = fmaf(w[(4 * c4 + 1) * 9 + t], v.y, s);
+      s = fmaf(w[(4 * c4 + 2) * 9 + t], v.z, s);
+      s = fmaf(w[(4 * c4 + 3) * 9 + t], v.w, s);
+    }
+  }
+  out[(size_t)(b * H + y0 + ty) * W + x0 + tx] = s;
+}
+
+// output conv input-gradient: g[q][ci] = sum_t w[ci][t] * sum_{p: clamp(p+t)=q} dsr[p]  (replicate adjoint)
+__global__ __launch_bounds__(256) void conv_out_dgrad_kernel(const float* __restrict__ dsr, const float* __restrict__ w,
+                                                             float* __restrict__ g, int B, int H, int W) {
+  const size_t n = (size_t)B * H * W;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+    const int qx = q % W, qy = (q / W) % H;
+    const size_t img = q - (size_t)qy * W - qx;
+    float S[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ty = t / 3 - 1, tx = t % 3 - 1;
+      int ys[2], ny = 0, xs[2], nx = 0;
+      if (qy - ty >= 0 && qy - ty < H) ys[ny++] = qy - ty;
+      if ((qy == 0 && ty == -1) || (qy == H - 1 && ty == 1)) ys[ny++] = qy;
+      if (qx - tx >= 0 && qx - tx < W) xs[nx++] = qx - tx;
+      if ((qx == 0 && tx == -1) || (qx == W - 1 && tx == 1)) xs[nx++] = qx;
+      float s = 0.f;
+      for (int iy = 0; iy < ny; ++iy)
+        for (int ix = 0; ix < nx; ++ix) s += dsr[img + (size_t)ys[iy] * W + xs[ix]];
+      S[t] = s;
+    }
+    float* gp = g + q * 16;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s = fmaf(w[(4 * c4 + j) * 9 + t], S[t], s);
+        o[j] = s;
+      }
+      st4(gp + 4 * c4, make_float4(o[0], o[1], o[2], o[3]));
+    }
+  }
+}
+
+// output conv weight/bias gradient: dW[ci][t] = sum dsr[p] * a[clamp(p+t)][ci]; db = sum dsr. 145 outputs.
+__global__ __launch_bounds__(256) void conv_out_wgrad_kernel(const float* __restrict__ y, const float* scale,
+                                                             const float* shift, const float* __restrict__ dsr,
+                                                             float* __restrict__ partials, int B, int H, int W) {
+  __shared__ float tile[324 * OCS];
+  __shared__ float dt[256];
+  const int tid = threadIdx.x;
+  const int tiles_x = W / 16, tiles_y = H / 16, ntiles = B * tiles_x * tiles_y;
+  const int ci = tid / 9, t = tid % 9;
+  const int off = ((t / 3) * 18 + t % 3) * OCS + (tid < 144 ? ci : 0);
+  float acc = 0.f;
+  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, b = tl / (tiles_x * tiles_y);
+    const int x0 = tx * 16, y0 = ty * 16;
+    __syncthreads();
+    stage_out_tile(tile, y, scale, shift, b, y0, x0, H, W, tid);
+    dt[tid] = dsr[(size_t)(b * H + y0 + (tid >> 4)) * W + x0 + (tid & 15)];
+    __syncthreads();
+    if (tid < 144) {
+      for (int p = 0; p < 256; ++p) acc = fmaf(dt[p], tile[((p >> 4) * 18 + (p & 15)) * OCS + off], acc);
+    } else if (tid == 144) {
+      for (int p = 0; p < 256; ++p) acc += dt[p];
+    }
+  }
+  if (tid < 145) partials[(size_t)blockIdx.x * 145 + tid] = acc;
+}
+
+// out[e] = sum_k partials[k][e] in float64, fixed order (deterministic)
+__global__ void sum_partials_kernel(const float* __restrict__ partials, int nblk, int n, float* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += (double)partials[(size_t)k * n + e];
+  out[e] = (float)s;
+}
+
+}  // namespace
+
+int launch_conv_in_fwd(const float* x, const float* w, float* y, float* partials, int B, int H, int W, hipStream_t s) {
+  if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
+  hipLaunchKernelGGL(conv_in_fwd_kernel, dim3(W / 16, H / 16, B), dim3(256), 0, s, x, w, y, partials, H, W);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_conv_in_wgrad(const float* x, const float* dy, float* partials, int nblk, float* dw, int B, int H, int W,
+                         hipStream_t s) {
+  if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
+  hipLaunchKernelGGL(conv_in_wgrad_kernel, dim3(nblk), dim3(256), 0, s, x, dy, partials, B, H, W);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(2), dim3(256), 0, s, partials, nblk, 288, dw);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_conv_out_fwd(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
+                        float* out, int B, int H, int W, hipStream_t s) {
+  if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
+  hipLaunchKernelGGL(conv_out_fwd_kernel, dim3(W / 16, H / 16, B), dim3(256), 0, s, y, scale, shift, w, bias, out, H, W);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_conv_out_dgrad(const float* dsr, const float* w, float* g, int B, int H, int W, hipStream_t s) {
+  const size_t n = (size_t)B * H * W;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(conv_out_dgrad_kernel, dim3(blocks), dim3(256), 0, s, dsr, w, g, B, H, W);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_conv_out_wgrad(const float* y, const float* scale, const float* shift, const float* dsr, float* partials,
+                          int nblk, float* dw, float* db, int B, int H, int W, hipStream_t s) {
+  if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
+  hipLaunchKernelGGL(conv_out_wgrad_kernel, dim3(nblk), dim3(256), 0, s, y, scale, shift, dsr, partials, B, H, W);
+  // dw (144 floats) and db (1 float) are adjacent in the flat gradient buffer (outlay.weight, outlay.bias)
+  if (db != dw + 144) return SIFSR_ERR_ARG;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partials, nblk, 145, dw);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_sum_partials(const float* partials, int nblk, int n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partials, nblk, n, out);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}

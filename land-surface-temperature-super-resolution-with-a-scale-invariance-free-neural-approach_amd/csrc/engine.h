@@ -1,0 +1,30 @@
+// Model-level schedule (internal; the C-ABI is include/sifsr_hip.h).
+#pragma once
+#include "common.h"
+#include "conv.h"
+#include "edge_conv.h"
+#include "loss.h"
+
+// All offsets in floats from the workspace base; every region is 256-byte aligned.
+struct WsLayout {
+  size_t npix[4];                         // B*H*W at the four resolution levels
+  size_t mean, invstd, scale, shift;      // per-channel vectors, all 17 BN layers back to back
+  size_t wfwd, wdg;                       // fragment-ordered conv weights (forward / dgrad)
+  size_t y[SIFSR_NUM_BN_LAYERS];          // raw conv outputs (pre-BN), NHWC
+  size_t P[3], R[3], U[3];                // pooled inputs, residual sums, upsampled decoder inputs
+  size_t partials;                        // BN statistic partials (scratch)
+  size_t fwd_end;
+  size_t c1, c0;                          // BN-backward affine coefficients
+  size_t g[SIFSR_NUM_BN_LAYERS];          // grad w.r.t. relu(bn(y_l)), overwritten in place by dy_l
+  size_t dyB[3];                          // dy of the residual blocks' second conv
+  size_t gP[3], gU[3];
+  size_t slabs;                           // wgrad per-workgroup partial dW (scratch)
+  size_t total;
+};
+
+int sifsr_layout(int B, int H, int W, int training, WsLayout* out);
+
+int sifsr_engine_forward(const float* x, float* sr, const float* params, float* running, long long* nbt, float* ws,
+                         size_t ws_floats, int B, int H, int W, int training, float momentum, float eps, hipStream_t s);
+int sifsr_engine_backward(const float* x, const float* dsr, const float* params, float* grads, float* ws,
+                          size_t ws_floats, int B, int H, int W, hipStream_t s);

@@ -1,0 +1,344 @@
+// ModelB_2 forward / backward as an explicit launch schedule on one HIP stream
+// (model.py:608-645 and its autograd transpose).  No allocation, no host sync: every buffer is a
+// fixed offset into a caller-provided workspace, so a whole step is hipGraph-capturable.
+//
+// Dataflow per Conv-BN-ReLU unit l (training):
+//   conv kernel: y_l = conv(a_in)            a_in = relu(y_prev*scale+shift) applied on load
+//                + per-workgroup (sum,sumsq) -> bn_finalize -> mean/invstd/scale/shift, running stats
+//   backward:    bn_bwd_reduce(g_l, y_l) -> bn_bwd_finalize -> dgamma, dbeta, (c1,c0)
+//                bn_bwd_apply: dy_l = scale*g_l*[z>0] + c1*y_l + c0
+//                wgrad(a_in, dy_l) -> slabs -> reduce -> dW;  dgrad(dy_l) (+ border fold) -> g of the inputs
+#include "engine.h"
+
+#include <stdio.h>
+
+// ---------------------------------------------------------------------------------------------
+// network table
+// ---------------------------------------------------------------------------------------------
+static NetTable build_net() {
+  static const int cin[SIFSR_NUM_BN_LAYERS] = {2, 16, 16, 16, 16, 32, 32, 32, 64, 64, 64, 128, 64, 64, 32, 32, 16};
+  static const int cout[SIFSR_NUM_BN_LAYERS] = {16, 16, 16, 16, 32, 32, 32, 64, 64, 64, 64, 64, 32, 32, 16, 16, 16};
+  static const int level[SIFSR_NUM_BN_LAYERS] = {0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 2, 2, 1, 1, 0, 0};
+  NetTable t;
+  int p = 0, r = 0, c = 0, wp = 0;
+  for (int l = 0; l < SIFSR_NUM_BN_LAYERS; ++l) {
+    LayerInfo& L = t.L[l];
+    L.cin = cin[l]; L.cout = cout[l]; L.level = level[l];
+    L.w_off = p; p += cout[l] * cin[l] * 9;
+    L.gamma_off = p; p += cout[l];
+    L.beta_off = p; p += cout[l];
+    L.run_off = r; r += 2 * cout[l];
+    L.ch_off = c; c += cout[l];
+    L.wpack_off = wp;
+    if (l > 0) wp += 9 * cin[l] * cout[l];
+  }
+  t.out_w_off = p; p += 144;
+  t.out_b_off = p; p += 1;
+  t.total_params = p; t.total_running = r; t.total_channels = c; t.total_wpack = wp;
+  return t;
+}
+const NetTable& sifsr_net() {
+  static const NetTable t = build_net();
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace layout
+// ---------------------------------------------------------------------------------------------
+static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }   // in floats (256 B)
+
+static int wgrad_blocks(int cin, int cout, int ntiles) {
+  const int cap = (size_t)9 * cin * cout <= 9216 ? 512 : 256;
+  return ntiles < cap ? ntiles : cap;
+}
+
+int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
+  if (B < 1 || H < 128 || W < 128 || H % 128 || W % 128) return SIFSR_ERR_SHAPE;
+  const NetTable& nt = sifsr_net();
+  WsLayout& w = *o;
+  size_t off = 0;
+  auto take = [&](size_t n) { const size_t r = off; off += align64(n); return r; };
+  size_t N[4];
+  N[0] = (size_t)B * H * W; N[1] = N[0] / 4; N[2] = N[0] / 16; N[3] = N[0] / 64;
+  for (int i = 0; i < 4; ++i) w.npix[i] = N[i];
+
+  w.mean = take(nt.total_channels); w.invstd = take(nt.total_channels);
+  w.scale = take(nt.total_channels); w.shift = take(nt.total_channels);
+  w.wfwd = take(nt.total_wpack); w.wdg = take(nt.total_wpack);
+  for (int l = 0; l < SIFSR_NUM_BN_LAYERS; ++l) w.y[l] = take(nt.L[l].cout * N[nt.L[l].level]);
+  static const int pc[3] = {16, 32, 64};
+  for (int k = 0; k < 3; ++k) {
+    w.P[k] = take(pc[k] * N[k + 1]);
+    w.R[k] = take(pc[k] * N[k + 1]);
+  }
+  w.U[0] = take(64 * N[2]); w.U[1] = take(32 * N[1]); w.U[2] = take(16 * N[0]);
+
+  // scratch: BN statistic partials (forward: one entry per conv workgroup; backward: <= 1024 blocks)
+  size_t maxpart = 0;
+  for (int l = 0; l < SIFSR_NUM_BN_LAYERS; ++l) {
+    const size_t nblk = N[nt.L[l].level] / 256;
+    const size_t n = (nblk > 1024 ? nblk : 1024) * nt.L[l].cout * 2;
+    maxpart = n > maxpart ? n : maxpart;
+  }
+  w.partials = take(maxpart);
+  w.fwd_end = off;
+  if (training) {
+    w.c1 = take(nt.total_channels); w.c0 = take(nt.total_channels);
+    for (int l = 0; l < SIFSR_NUM_BN_LAYERS; ++l) w.g[l] = take(nt.L[l].cout * N[nt.L[l].level]);
+    w.dyB[0] = take(16 * N[1]); w.dyB[1] = take(32 * N[2]); w.dyB[2] = take(64 * N[3]);
+    for (int k = 0; k < 3; ++k) w.gP[k] = take(pc[k] * N[k + 1]);
+    w.gU[0] = take(64 * N[2]); w.gU[1] = take(32 * N[1]); w.gU[2] = take(16 * N[0]);
+    size_t maxslab = 1024 * 288;   // edge-layer partials
+    for (int l = 1; l < SIFSR_NUM_BN_LAYERS; ++l) {
+      const int ntiles = (int)(N[nt.L[l].level] / 128);
+      const size_t n = (size_t)wgrad_blocks(nt.L[l].cin, nt.L[l].cout, ntiles) * 9 * nt.L[l].cin * nt.L[l].cout;
+      maxslab = n > maxslab ? n : maxslab;
+    }
+    w.slabs = take(maxslab);
+  }
+  w.total = off;
+  return SIFSR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Ctx {
+  const NetTable& nt;
+  WsLayout lay;
+  float* ws;
+  const float* params;
+  int B, H, W;
+  hipStream_t s;
+  int lvH(int lv) const { return H >> lv; }
+  int lvW(int lv) const { return W >> lv; }
+  float* f(size_t off) const { return ws + off; }
+  const float* scale(int l) const { return ws + lay.scale + nt.L[l].ch_off; }
+  const float* shift(int l) const { return ws + lay.shift + nt.L[l].ch_off; }
+};
+
+ConvSrc src_raw(const float* p, int C) { ConvSrc s; s.ptr = p; s.scale = nullptr; s.shift = nullptr; s.C = C; s.coff = 0; s.nq = C / 16; return s; }
+ConvSrc src_act(const Ctx& c, int l) {
+  ConvSrc s; s.ptr = c.f(c.lay.y[l]); s.scale = c.scale(l); s.shift = c.shift(l); s.C = c.nt.L[l].cout; s.coff = 0; s.nq = s.C / 16; return s;
+}
+ConvSrc src_none() { ConvSrc s; s.ptr = nullptr; s.scale = nullptr; s.shift = nullptr; s.C = 0; s.coff = 0; s.nq = 0; return s; }
+
+#define SIFSR_TRY(expr) do { int rc__ = (expr); if (rc__ != SIFSR_OK) return rc__; } while (0)
+
+// forward of one MFMA Conv(-BN) unit
+int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, float* running, float momentum, float eps) {
+  const LayerInfo& L = c.nt.L[l];
+  ConvArgs a;
+  a.src[0] = s0; a.src[1] = s1;
+  a.dst[0].ptr = c.f(c.lay.y[l]); a.dst[0].C = L.cout; a.dst[0].coff = 0;
+  a.dst[1] = a.dst[0];
+  a.wpack = c.f(c.lay.wfwd) + L.wpack_off;
+  a.addend = nullptr; a.addC = 0;
+  a.stat_partials = training ? c.f(c.lay.partials) : nullptr;
+  a.dst_split = L.cout / 16;
+  a.B = c.B; a.H = c.lvH(L.level); a.W = c.lvW(L.level);
+  a.NQ = L.cin / 16;
+  SIFSR_TRY(launch_conv3x3_mfma(a, L.cout, 0, c.s));
+  if (training) {
+    const int nblk = c.B * (a.H / 16) * (a.W / 16);
+    SIFSR_TRY(launch_bn_finalize(c.f(c.lay.partials), nblk, L.cout, (double)c.B * a.H * a.W, c.params + L.gamma_off,
+                                 c.params + L.beta_off, running + L.run_off, running + L.run_off + L.cout, momentum, eps,
+                                 c.f(c.lay.mean) + L.ch_off, c.f(c.lay.invstd) + L.ch_off,
+                                 c.f(c.lay.scale) + L.ch_off, c.f(c.lay.shift) + L.ch_off, c.s));
+  }
+  return SIFSR_OK;
+}
+
+// BatchNorm+ReLU backward of unit l: g (grad w.r.t. relu(bn(y_l))) -> dy (grad w.r.t. y_l); dgamma/dbeta -> grads
+int bn_unit_bwd(const Ctx& c, int l, const float* g, float* dy, float* grads) {
+  const LayerInfo& L = c.nt.L[l];
+  const size_t npix = c.lay.npix[L.level];
+  size_t nb = npix / 256;
+  const int nblk = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+  const float* y = c.f(c.lay.y[l]);
+  SIFSR_TRY(launch_bn_bwd_reduce(g, y, c.scale(l), c.shift(l), c.f(c.lay.mean) + L.ch_off, c.f(c.lay.invstd) + L.ch_off,
+                                 L.cout, npix, c.f(c.lay.partials), nblk, c.s));
+  SIFSR_TRY(launch_bn_bwd_finalize(c.f(c.lay.partials), nblk, L.cout, (double)npix, c.scale(l), c.f(c.lay.mean) + L.ch_off,
+                                   c.f(c.lay.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
+                                   c.f(c.lay.c1) + L.ch_off, c.f(c.lay.c0) + L.ch_off, c.s));
+  SIFSR_TRY(launch_bn_bwd_apply(g, y, c.scale(l), c.shift(l), c.f(c.lay.c1) + L.ch_off, c.f(c.lay.c0) + L.ch_off, L.cout,
+                                npix, dy, c.s));
+  return SIFSR_OK;
+}
+
+// weight gradient of MFMA unit l from its forward inputs and dy
+int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy, float* grads) {
+  const LayerInfo& L = c.nt.L[l];
+  WgradArgs a;
+  a.src[0] = s0; a.src[1] = s1;
+  a.dy = dy; a.slabs = c.f(c.lay.slabs);
+  a.B = c.B; a.H = c.lvH(L.level); a.W = c.lvW(L.level);
+  a.NQ = L.cin / 16;
+  a.ntiles = c.B * (a.H / 8) * (a.W / 16);
+  const int nblk = wgrad_blocks(L.cin, L.cout, a.ntiles);
+  SIFSR_TRY(launch_conv3x3_wgrad(a, L.cin, L.cout, nblk, c.s));
+  SIFSR_TRY(launch_wgrad_reduce(a.slabs, nblk, L.cin, L.cout, grads + L.w_off, c.s));
+  return SIFSR_OK;
+}
+
+// input gradient of MFMA unit l: g_in = conv^T(dy) with the replicate-border fold.
+// Output channels [0, split_ch) -> (g0, C0); the rest -> (g1, C1).  addend (C = cin) is added to g0.
+int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int split_ch, float* g1, int C1,
+                    const float* addend) {
+  const LayerInfo& L = c.nt.L[l];
+  ConvArgs a;
+  a.src[0] = src_raw(dy, L.cout); a.src[1] = src_none();
+  a.dst[0].ptr = g0; a.dst[0].C = C0; a.dst[0].coff = 0;
+  a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
+  a.wpack = c.f(c.lay.wdg) + L.wpack_off;
+  a.addend = addend; a.addC = L.cin;
+  a.stat_partials = nullptr;
+  a.dst_split = split_ch / 16;
+  a.B = c.B; a.H = c.lvH(L.level); a.W = c.lvW(L.level);
+  a.NQ = L.cout / 16;
+  SIFSR_TRY(launch_conv3x3_mfma(a, L.cin, 1, c.s));
+  SIFSR_TRY(launch_dgrad_border_fix(dy, L.cout, c.params + L.w_off, L.cin, g0, C0, 0, split_ch, g1 ? g1 : g0,
+                                    g1 ? C1 : C0, 0, c.B, a.H, a.W, c.s));
+  return SIFSR_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+int sifsr_engine_forward(const float* x, float* sr, const float* params, float* running, long long* nbt, float* ws,
+                         size_t ws_floats, int B, int H, int W, int training, float momentum, float eps,
+                         hipStream_t s) {
+  if (!x || !sr || !params || !running || !ws) return SIFSR_ERR_ARG;
+  Ctx c{sifsr_net(), WsLayout(), ws, params, B, H, W, s};
+  SIFSR_TRY(sifsr_layout(B, H, W, training, &c.lay));
+  if (ws_floats < c.lay.total) return SIFSR_ERR_WORKSPACE;
+  const NetTable& nt = c.nt;
+  const WsLayout& w = c.lay;
+
+  SIFSR_TRY(launch_pack_weights(params, c.f(w.wfwd), c.f(w.wdg), s));
+  if (training) {
+    if (nbt) SIFSR_TRY(launch_nbt_increment(nbt, SIFSR_NUM_BN_LAYERS, s));
+  } else {
+    SIFSR_TRY(launch_bn_eval_coeffs(params, running, eps, c.f(w.scale), c.f(w.shift), s));
+  }
+
+  // inbloc (DoubleConvolution, model.py:596)
+  {
+    const LayerInfo& L = nt.L[L_IN0];
+    SIFSR_TRY(launch_conv_in_fwd(x, params + L.w_off, c.f(w.y[L_IN0]), training ? c.f(w.partials) : nullptr, B, H, W, s));
+    if (training)
+      SIFSR_TRY(launch_bn_finalize(c.f(w.partials), B * (H / 16) * (W / 16), 16, (double)B * H * W, params + L.gamma_off,
+                                   params + L.beta_off, running + L.run_off, running + L.run_off + 16, momentum, eps,
+                                   c.f(w.mean) + L.ch_off, c.f(w.invstd) + L.ch_off, c.f(w.scale) + L.ch_off,
+                                   c.f(w.shift) + L.ch_off, s));
+  }
+  SIFSR_TRY(conv_unit_fwd(c, L_IN3, src_act(c, L_IN0), src_none(), training, running, momentum, eps));
+
+  // encoder: DownBlock_pool x3 (model.py:597-599, :528-531)
+  static const int enc_prev[3] = {L_IN3, L_D1C, L_D2C};
+  static const int enc_a[3] = {L_D1A, L_D2A, L_D3A}, enc_b[3] = {L_D1B, L_D2B, L_D3B}, enc_c[3] = {L_D1C, L_D2C, L_D3C};
+  static const int pc[3] = {16, 32, 64};
+  for (int k = 0; k < 3; ++k) {
+    const int lp = enc_prev[k];
+    SIFSR_TRY(launch_bnrelu_pool2(c.f(w.y[lp]), c.scale(lp), c.shift(lp), c.f(w.P[k]), B, c.lvH(k), c.lvW(k), pc[k], s));
+    SIFSR_TRY(conv_unit_fwd(c, enc_a[k], src_raw(c.f(w.P[k]), pc[k]), src_none(), training, running, momentum, eps));
+    SIFSR_TRY(conv_unit_fwd(c, enc_b[k], src_act(c, enc_a[k]), src_none(), training, running, momentum, eps));
+    SIFSR_TRY(launch_bnrelu_add(c.f(w.P[k]), c.f(w.y[enc_b[k]]), c.scale(enc_b[k]), c.shift(enc_b[k]), c.f(w.R[k]), pc[k],
+                                w.npix[k + 1], s));
+    SIFSR_TRY(conv_unit_fwd(c, enc_c[k], src_raw(c.f(w.R[k]), pc[k]), src_none(), training, running, momentum, eps));
+  }
+
+  // decoder: UpBlock x3 (model.py:601-603, :235-248); cat([up, skip], 1)
+  static const int dec_low[3] = {L_D3C, L_U1B, L_U2B}, dec_skip[3] = {L_D2C, L_D1C, L_IN3};
+  static const int dec_a[3] = {L_U1A, L_U2A, L_U3A}, dec_b[3] = {L_U1B, L_U2B, L_U3B};
+  static const int uc[3] = {64, 32, 16};
+  for (int k = 0; k < 3; ++k) {
+    const int lv = 2 - k;   // output level of this UpBlock
+    const int ll = dec_low[k];
+    SIFSR_TRY(launch_bnrelu_up2x(c.f(w.y[ll]), c.scale(ll), c.shift(ll), c.f(w.U[k]), B, c.lvH(lv + 1), c.lvW(lv + 1), uc[k], s));
+    SIFSR_TRY(conv_unit_fwd(c, dec_a[k], src_raw(c.f(w.U[k]), uc[k]), src_act(c, dec_skip[k]), training, running, momentum, eps));
+    SIFSR_TRY(conv_unit_fwd(c, dec_b[k], src_act(c, dec_a[k]), src_none(), training, running, momentum, eps));
+  }
+
+  // outlay (model.py:605)
+  SIFSR_TRY(launch_conv_out_fwd(c.f(w.y[L_U3B]), c.scale(L_U3B), c.shift(L_U3B), params + nt.out_w_off,
+                                params + nt.out_b_off, sr, B, H, W, s));
+  return SIFSR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward (requires the workspace of the matching training-mode forward)
+// ---------------------------------------------------------------------------------------------
+int sifsr_engine_backward(const float* x, const float* dsr, const float* params, float* grads, float* ws,
+                          size_t ws_floats, int B, int H, int W, hipStream_t s) {
+  if (!x || !dsr || !params || !grads || !ws) return SIFSR_ERR_ARG;
+  Ctx c{sifsr_net(), WsLayout(), ws, params, B, H, W, s};
+  SIFSR_TRY(sifsr_layout(B, H, W, 1, &c.lay));
+  if (ws_floats < c.lay.total) return SIFSR_ERR_WORKSPACE;
+  const NetTable& nt = c.nt;
+  const WsLayout& w = c.lay;
+
+  // outlay
+  {
+    int nblk = B * (H / 16) * (W / 16);
+    if (nblk > 1024) nblk = 1024;
+    SIFSR_TRY(launch_conv_out_wgrad(c.f(w.y[L_U3B]), c.scale(L_U3B), c.shift(L_U3B), dsr, c.f(w.slabs), nblk,
+                                    grads + nt.out_w_off, grads + nt.out_b_off, B, H, W, s));
+    SIFSR_TRY(launch_conv_out_dgrad(dsr, params + nt.out_w_off, c.f(w.g[L_U3B]), B, H, W, s));
+  }
+
+  // decoder, last to first
+  static const int dec_low[3] = {L_D3C, L_U1B, L_U2B}, dec_skip[3] = {L_D2C, L_D1C, L_IN3};
+  static const int dec_a[3] = {L_U1A, L_U2A, L_U3A}, dec_b[3] = {L_U1B, L_U2B, L_U3B};
+  static const int uc[3] = {64, 32, 16};
+  for (int k = 2; k >= 0; --k) {
+    const int lv = 2 - k;
+    const int la = dec_a[k], lb = dec_b[k], ls = dec_skip[k], ll = dec_low[k];
+    // second conv of the DoubleConvolution
+    SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), c.f(w.g[lb]), grads));
+    SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads));
+    SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), nt.L[la].cout, nt.L[lb].cin, nullptr, 0, nullptr));
+    // first conv: input = cat([U_k, relu(bn(y_skip))])
+    SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), c.f(w.g[la]), grads));
+    SIFSR_TRY(conv_unit_wgrad(c, la, src_raw(c.f(w.U[k]), uc[k]), src_act(c, ls), c.f(w.g[la]), grads));
+    SIFSR_TRY(conv_unit_dgrad(c, la, c.f(w.g[la]), c.f(w.gU[k]), uc[k], uc[k], c.f(w.g[ls]), nt.L[ls].cout, nullptr));
+    SIFSR_TRY(launch_up2x_bwd(c.f(w.gU[k]), c.f(w.g[ll]), B, c.lvH(lv + 1), c.lvW(lv + 1), uc[k], s));
+  }
+
+  // encoder, last to first
+  static const int enc_prev[3] = {L_IN3, L_D1C, L_D2C};
+  static const int enc_a[3] = {L_D1A, L_D2A, L_D3A}, enc_b[3] = {L_D1B, L_D2B, L_D3B}, enc_c[3] = {L_D1C, L_D2C, L_D3C};
+  static const int pc[3] = {16, 32, 64};
+  for (int k = 2; k >= 0; --k) {
+    const int la = enc_a[k], lb = enc_b[k], lc = enc_c[k], lp = enc_prev[k];
+    // lastconv: input R_k = P_k + relu(bn(y_b)); its gradient is both g(a_b) and part of g(P_k)
+    SIFSR_TRY(bn_unit_bwd(c, lc, c.f(w.g[lc]), c.f(w.g[lc]), grads));
+    SIFSR_TRY(conv_unit_wgrad(c, lc, src_raw(c.f(w.R[k]), pc[k]), src_none(), c.f(w.g[lc]), grads));
+    SIFSR_TRY(conv_unit_dgrad(c, lc, c.f(w.g[lc]), c.f(w.g[lb]), pc[k], pc[k], nullptr, 0, nullptr));
+    // residual DoubleConvolution (g[lb] must survive as the skip gradient -> dy goes to dyB)
+    SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), c.f(w.dyB[k]), grads));
+    SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.dyB[k]), grads));
+    SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.dyB[k]), c.f(w.g[la]), pc[k], pc[k], nullptr, 0, nullptr));
+    SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), c.f(w.g[la]), grads));
+    SIFSR_TRY(conv_unit_wgrad(c, la, src_raw(c.f(w.P[k]), pc[k]), src_none(), c.f(w.g[la]), grads));
+    SIFSR_TRY(conv_unit_dgrad(c, la, c.f(w.g[la]), c.f(w.gP[k]), pc[k], pc[k], nullptr, 0, c.f(w.g[lb])));
+    // AvgPool adjoint, accumulated onto the skip gradient written by the decoder
+    SIFSR_TRY(launch_pool2_bwd(c.f(w.gP[k]), c.f(w.g[lp]), B, c.lvH(k), c.lvW(k), pc[k], 1, s));
+  }
+
+  // inbloc
+  SIFSR_TRY(bn_unit_bwd(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN3]), grads));
+  SIFSR_TRY(conv_unit_wgrad(c, L_IN3, src_act(c, L_IN0), src_none(), c.f(w.g[L_IN3]), grads));
+  SIFSR_TRY(conv_unit_dgrad(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), 16, 16, nullptr, 0, nullptr));
+  SIFSR_TRY(bn_unit_bwd(c, L_IN0, c.f(w.g[L_IN0]), c.f(w.g[L_IN0]), grads));
+  {
+    int nblk = B * (H / 16) * (W / 16);
+    if (nblk > 1024) nblk = 1024;
+    SIFSR_TRY(launch_conv_in_wgrad(x, c.f(w.g[L_IN0]), c.f(w.slabs), nblk, grads + nt.L[L_IN0].w_off, B, H, W, s));
+  }
+  return SIFSR_OK;
+}

@@ -1,0 +1,182 @@
+// Resampling glue of the U-Net (all NHWC fp32, one thread per (pixel, channel quad)):
+//   * AvgPool2d(2,2) of relu(bn(y))                        -- DownBlock_pool, model.py:504
+//   * residual sum  x + relu(bn(DoubleConv(x)))            -- ResidualConnection, model.py:311-312
+//   * Upsample(x2, bilinear, align_corners=True) of relu(bn(y)) -- UpBlock, model.py:207
+// and their adjoints.  The BatchNorm+ReLU of the producing layer is folded in (scale/shift), so the
+// normalised activation itself is never written to HBM.
+#include "edge_conv.h"
+
+namespace {
+
+__device__ __forceinline__ float4 maybe_bnrelu(float4 v, const float* scale, const float* shift, int c) {
+  return scale != nullptr ? bn_relu4(v, ld4(scale + c), ld4(shift + c)) : v;
+}
+
+__global__ void bnrelu_pool2_kernel(const float* __restrict__ y, const float* scale, const float* shift,
+                                    float* __restrict__ out, int B, int H, int W, int C) {
+  const int Q = C / 4, Ho = H / 2, Wo = W / 2;
+  const size_t n = (size_t)B * Ho * Wo * Q;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % Q) * 4;
+    const size_t p = e / Q;
+    const int ox = p % Wo, oy = (p / Wo) % Ho, b = p / ((size_t)Wo * Ho);
+    const float* s = y + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+    const float4 v00 = maybe_bnrelu(ld4(s), scale, shift, c), v01 = maybe_bnrelu(ld4(s + C), scale, shift, c);
+    const float4 v10 = maybe_bnrelu(ld4(s + (size_t)W * C), scale, shift, c);
+    const float4 v11 = maybe_bnrelu(ld4(s + (size_t)W * C + C), scale, shift, c);
+    float4 o;
+    o.x = (v00.x + v01.x + v10.x + v11.x) * 0.25f;
+    o.y = (v00.y + v01.y + v10.y + v11.y) * 0.25f;
+    o.z = (v00.z + v01.z + v10.z + v11.z) * 0.25f;
+    o.w = (v00.w + v01.w + v10.w + v11.w) * 0.25f;
+    st4(out + p * C + c, o);
+  }
+}
+
+__global__ void bnrelu_add_kernel(const float* __restrict__ p, const float* __restrict__ y, const float* scale,
+                                  const float* shift, float* __restrict__ out, int C, size_t nquads) {
+  const int Q = C / 4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nquads; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % Q) * 4;
+    const float4 a = ld4(p + e * 4), v = maybe_bnrelu(ld4(y + e * 4), scale, shift, c);
+    st4(out + e * 4, make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w));
+  }
+}
+
+// source index / weights of the align_corners=True bilinear x2 upsample for output coordinate o
+// (ATen upsample_bilinear2d: ratio = (in-1)/(out-1); src = ratio*o; i0 = (int)src; lambda = src - i0)
+__device__ __forceinline__ void up_coord(int o, int in, int out, int& i0, int& i1, float& l0, float& l1) {
+  const float ratio = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float src = ratio * (float)o;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+__global__ void bnrelu_up2x_kernel(const float* __restrict__ y, const float* scale, const float* shift,
+                                   float* __restrict__ out, int B, int Hin, int Win, int C) {
+  const int Q = C / 4, Ho = 2 * Hin, Wo = 2 * Win;
+  const size_t n = (size_t)B * Ho * Wo * Q;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % Q) * 4;
+    const size_t p = e / Q;
+    const int ox = p % Wo, oy = (p / Wo) % Ho, b = p / ((size_t)Wo * Ho);
+    int y0, y1, x0, x1; float hy0, hy1, hx0, hx1;
+    up_coord(oy, Hin, Ho, y0, y1, hy0, hy1);
+    up_coord(ox, Win, Wo, x0, x1, hx0, hx1);
+    const float* base = y + (size_t)b * Hin * Win * C + c;
+    const float4 v00 = maybe_bnrelu(ld4(base + ((size_t)y0 * Win + x0) * C), scale, shift, c);
+    const float4 v01 = maybe_bnrelu(ld4(base + ((size_t)y0 * Win + x1) * C), scale, shift, c);
+    const float4 v10 = maybe_bnrelu(ld4(base + ((size_t)y1 * Win + x0) * C), scale, shift, c);
+    const float4 v11 = maybe_bnrelu(ld4(base + ((size_t)y1 * Win + x1) * C), scale, shift, c);
+    float4 o;
+    o.x = hy0 * (hx0 * v00.x + hx1 * v01.x) + hy1 * (hx0 * v10.x + hx1 * v11.x);
+    o.y = hy0 * (hx0 * v00.y + hx1 * v01.y) + hy1 * (hx0 * v10.y + hx1 * v11.y);
+    o.z = hy0 * (hx0 * v00.z + hx1 * v01.z) + hy1 * (hx0 * v10.z + hx1 * v11.z);
+    o.w = hy0 * (hx0 * v00.w + hx1 * v01.w) + hy1 * (hx0 * v10.w + hx1 * v11.w);
+    st4(out + p * C + c, o);
+  }
+}
+
+// adjoint of AvgPool2d(2,2): g[y][x] (+)= 0.25 * gp[y/2][x/2]
+__global__ void pool2_bwd_kernel(const float* __restrict__ gp, float* __restrict__ g, int B, int H, int W, int C,
+                                 int accumulate) {
+  const int Q = C / 4, Ho = H / 2, Wo = W / 2;
+  const size_t n = (size_t)B * H * W * Q;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % Q) * 4;
+    const size_t p = e / Q;
+    const int x = p % W, yy = (p / W) % H, b = p / ((size_t)W * H);
+    const float4 v = ld4(gp + (((size_t)b * Ho + yy / 2) * Wo + x / 2) * C + c);
+    float4 o = make_float4(0.25f * v.x, 0.25f * v.y, 0.25f * v.z, 0.25f * v.w);
+    if (accumulate) {
+      const float4 a = ld4(g + p * C + c);
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
+    st4(g + p * C + c, o);
+  }
+}
+
+// adjoint of the bilinear x2 upsample, gather form (deterministic): every low-res pixel collects the
+// high-res pixels whose two source taps include it (output rows 2i-2 .. 2i+2 are the only candidates
+// because ratio < 1/2).
+__global__ void up2x_bwd_kernel(const float* __restrict__ gu, float* __restrict__ g, int B, int Hin, int Win, int C) {
+  const int Q = C / 4, Ho = 2 * Hin, Wo = 2 * Win;
+  const size_t n = (size_t)B * Hin * Win * Q;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % Q) * 4;
+    const size_t p = e / Q;
+    const int ix = p % Win, iy = (p / Win) % Hin, b = p / ((size_t)Win * Hin);
+    float wy[5], wx[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int oy = 2 * iy - 2 + k, ox = 2 * ix - 2 + k;
+      wy[k] = 0.f; wx[k] = 0.f;
+      if (oy >= 0 && oy < Ho) {
+        int a0, a1; float l0, l1;
+        up_coord(oy, Hin, Ho, a0, a1, l0, l1);
+        wy[k] = (a0 == iy ? l0 : 0.f) + (a1 == iy ? l1 : 0.f);
+      }
+      if (ox >= 0 && ox < Wo) {
+        int a0, a1; float l0, l1;
+        up_coord(ox, Win, Wo, a0, a1, l0, l1);
+        wx[k] = (a0 == ix ? l0 : 0.f) + (a1 == ix ? l1 : 0.f);
+      }
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      if (wy[ky] == 0.f) continue;
+      const int oy = 2 * iy - 2 + ky;
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        if (wx[kx] == 0.f) continue;
+        const int ox = 2 * ix - 2 + kx;
+        const float w = wy[ky] * wx[kx];
+        const float4 v = ld4(gu + (((size_t)b * Ho + oy) * Wo + ox) * C + c);
+        acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+      }
+    }
+    st4(g + p * C + c, acc);
+  }
+}
+
+inline int grid_for(size_t n) {
+  size_t b = (n + 255) / 256;
+  return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+int launch_bnrelu_pool2(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W, int C, hipStream_t s) {
+  if (H % 2 || W % 2 || C % 4) return SIFSR_ERR_SHAPE;
+  hipLaunchKernelGGL(bnrelu_pool2_kernel, dim3(grid_for((size_t)B * H / 2 * W / 2 * C / 4)), dim3(256), 0, s, y, scale, shift, out, B, H, W, C);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+int launch_bnrelu_add(const float* p, const float* y, const float* scale, const float* shift, float* out, int C, size_t npix, hipStream_t s) {
+  if (C % 4) return SIFSR_ERR_SHAPE;
+  const size_t nq = npix * C / 4;
+  hipLaunchKernelGGL(bnrelu_add_kernel, dim3(grid_for(nq)), dim3(256), 0, s, p, y, scale, shift, out, C, nq);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+int launch_bnrelu_up2x(const float* y, const float* scale, const float* shift, float* out, int B, int Hin, int Win, int C, hipStream_t s) {
+  if (C % 4) return SIFSR_ERR_SHAPE;
+  hipLaunchKernelGGL(bnrelu_up2x_kernel, dim3(grid_for((size_t)B * Hin * Win * C)), dim3(256), 0, s, y, scale, shift, out, B, Hin, Win, C);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+int launch_pool2_bwd(const float* gp, float* g, int B, int H, int W, int C, int accumulate, hipStream_t s) {
+  if (H % 2 || W % 2 || C % 4) return SIFSR_ERR_SHAPE;
+  hipLaunchKernelGGL(pool2_bwd_kernel, dim3(grid_for((size_t)B * H * W * C / 4)), dim3(256), 0, s, gp, g, B, H, W, C, accumulate);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+int launch_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, hipStream_t s) {
+  if (C % 4) return SIFSR_ERR_SHAPE;
+  hipLaunchKernelGGL(up2x_bwd_kernel, dim3(grid_for((size_t)B * Hin * Win * C / 4)), dim3(256), 0, s, gu, g, B, Hin, Win, C);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}

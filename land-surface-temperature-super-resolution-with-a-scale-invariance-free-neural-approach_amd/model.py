@@ -1,0 +1,243 @@
+"""``ModelB_2`` -- drop-in for the reference's ``model.ModelB_2`` (model.py:533-645) on MI355X.
+
+Same constructor signature, attributes and 104-key ``state_dict`` (SURVEY.md §8 b); the module tree
+(``inbloc.bloc.{0,1,3,4}``, ``db{1,2,3}.resblock.doubleconv.bloc.*``, ``db{1,2,3}.lastconv.{0,1}``,
+``ub{1,2,3}.convbloc.bloc.*``, ``outlay``) is kept ONLY as a parameter container built from stock
+``torch.nn`` modules -- their ``forward`` is never called.  ``ModelB_2.forward`` runs the whole
+network as one launch schedule of hand-written gfx950 kernels behind the C ABI
+(``sifsr_model_forward`` / ``sifsr_model_backward``, include/sifsr_hip.h); PyTorch provides device
+memory, the stream and the autograd edge, nothing else.
+
+All parameters are views into ONE flat fp32 buffer in ``parameters()`` order (so the optimizer and
+the data-parallel gradient all-reduce see a single contiguous tensor); gradients come back the same
+way.  There is no CPU path: calling the module on a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import _lib
+
+_DEFAULT_DOWN = [16, 32, 64, 128]
+
+
+def _conv(cin, cout, padding_mode, bias=False):
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1, padding_mode=padding_mode, bias=bias)
+
+
+class _Bloc(nn.Module):
+    """Parameter container with the reference's ``.bloc`` Sequential (Conv, BN, ReLU) x 2 -- model.py:134-141."""
+
+    def __init__(self, cin, cout, mid, padding_mode):
+        super().__init__()
+        mid = mid or cout
+        self.bloc = nn.Sequential(_conv(cin, mid, padding_mode), nn.BatchNorm2d(mid), nn.ReLU(),
+                                  _conv(mid, cout, padding_mode), nn.BatchNorm2d(cout), nn.ReLU())
+
+
+class _Res(nn.Module):
+    def __init__(self, c, padding_mode):
+        super().__init__()
+        self.doubleconv = _Bloc(c, c, None, padding_mode)            # model.py:289
+
+
+class _Down(nn.Module):
+    def __init__(self, cin, cout, padding_mode):
+        super().__init__()
+        self.downsampling = nn.AvgPool2d(kernel_size=2, stride=2)     # model.py:504
+        self.resblock = _Res(cin, padding_mode)                       # model.py:505
+        self.lastconv = nn.Sequential(_conv(cin, cout, padding_mode), nn.BatchNorm2d(cout), nn.ReLU())  # :506-509
+
+
+class _Up(nn.Module):
+    def __init__(self, cin, cout, padding_mode):
+        super().__init__()
+        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)   # model.py:207
+        self.convbloc = _Bloc(cin, cout, cin // 2, padding_mode)                     # model.py:208
+
+
+class _ModelFn(torch.autograd.Function):
+    """One autograd node for the whole network: forward / backward are single C-ABI calls."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        _lib.require_gpu(x, "ModelB_2 input")
+        B, C, H, W = x.shape
+        if C != 2:
+            raise _lib.SifsrError(f"ModelB_2 expects (B,2,H,W) = cat(lst_up, ndvi); got {tuple(x.shape)}")
+        if H % 128 or W % 128:
+            raise _lib.SifsrError("H and W must be multiples of 128 (reference patches are 256x256)")
+        flat_p, flat_r, flat_n = module._flat_state(x.device)
+        training = bool(module.training)
+        need_bwd = training and any(ctx.needs_input_grad)   # grad mode is off inside forward(); this is the caller's
+        ws_bytes = _lib.call("sifsr_model_workspace_bytes", B, H, W, 1 if need_bwd else 0)
+        if ws_bytes == 0:
+            raise _lib.SifsrError(f"unsupported shape {tuple(x.shape)}")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        sr = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+        bn = module._bn_hyper
+        _lib.call("sifsr_model_forward", x, sr, flat_p, flat_r, flat_n, ws, ws_bytes, B, H, W,
+                  1 if training else 0, bn[0], bn[1], _lib.stream_ptr(x.device))
+        ctx.module = module
+        ctx.can_bwd = need_bwd
+        ctx.training = training
+        if need_bwd:
+            ctx.ws = ws
+            ctx.x = x
+            ctx.shape = (B, H, W)
+            ctx.param_version = module._flat_version
+        return sr
+
+    @staticmethod
+    def backward(ctx, dsr):
+        module = ctx.module
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode (running-statistics) BatchNorm is not implemented; "
+                                      "call model.train() for training, or torch.inference_mode() for prediction")
+        if not ctx.can_bwd:
+            raise _lib.SifsrError("backward called on a forward that did not keep its workspace")
+        if ctx.ws is None:
+            raise _lib.SifsrError("backward called twice on the same forward (workspace already released)")
+        B, H, W = ctx.shape
+        dsr = dsr.contiguous()
+        flat_p, _, _ = module._flat_state(dsr.device)
+        grads = torch.empty_like(flat_p)
+        _lib.call("sifsr_model_backward", ctx.x, dsr, flat_p, grads, ctx.ws, ctx.ws.numel(), B, H, W,
+                  _lib.stream_ptr(dsr.device))
+        ctx.ws = None
+        ctx.x = None
+        module._last_flat_grad = grads
+        outs = [grads[o:o + n].view(s) for (o, n, s) in module._param_slices]
+        return (None, None, *outs)
+
+
+class ModelB_2(nn.Module):
+    """Drop-in for ``model.ModelB_2`` (model.py:563): same ctor args, attributes and state_dict.
+
+    Only the configuration the reference ships is implemented natively: ``padding_mode='replicate'``,
+    ``activation='ReLU'``, ``bilinear`` true, ``downchannels=[16,32,64,128]``, ``in_channels=2``;
+    anything else raises ``NotImplementedError`` at construction.
+    """
+
+    def __init__(self, in_channels, downchannels=_DEFAULT_DOWN, padding_mode="replicate", activation="ReLU",
+                 bilinear=True, n_bridge_blocks=1):
+        super().__init__()
+        if padding_mode != "replicate":
+            raise NotImplementedError("only padding_mode='replicate' has gfx950 kernels")
+        if activation != "ReLU":
+            raise NotImplementedError("only activation='ReLU' has gfx950 kernels")
+        if not bilinear:
+            raise NotImplementedError("only the bilinear UpBlock (bilinear=1) has gfx950 kernels")
+        if list(downchannels) != _DEFAULT_DOWN or in_channels != 2:
+            raise NotImplementedError("the native schedule is specialised for in_channels=2, downchannels=[16,32,64,128]")
+        # attributes set by the reference ctor (model.py:587-592)
+        self.in_channels = in_channels
+        self.downchannels = downchannels
+        self.padding = padding_mode
+        self.activation = activation
+        self.upfactor = 2 if bilinear else 1
+        self.bridge = n_bridge_blocks
+        d, uf = downchannels, self.upfactor
+        self.inbloc = _Bloc(in_channels, d[0], None, padding_mode)          # model.py:596
+        self.db1 = _Down(d[0], d[1], padding_mode)                           # :597
+        self.db2 = _Down(d[1], d[2], padding_mode)                           # :598
+        self.db3 = _Down(d[2], d[3] // uf, padding_mode)                     # :599
+        self.ub1 = _Up(d[3], d[2] // uf, padding_mode)                       # :601
+        self.ub2 = _Up(d[2], d[1] // uf, padding_mode)                       # :602
+        self.ub3 = _Up(d[1], d[0], padding_mode)                             # :603
+        self.outlay = _conv(d[0], 1, padding_mode, bias=True)                # :605
+        self._init_flat_bookkeeping()
+
+    # ---- flat-buffer bookkeeping ---------------------------------------------------------------
+    def _init_flat_bookkeeping(self):
+        object.__setattr__(self, "_flat", None)          # (params, running, nbt) tensors; not registered
+        object.__setattr__(self, "_flat_version", 0)
+        object.__setattr__(self, "_last_flat_grad", None)
+        off, slices = 0, []
+        for p in self.parameters():
+            slices.append((off, p.numel(), tuple(p.shape)))
+            off += p.numel()
+        object.__setattr__(self, "_param_slices", slices)
+        object.__setattr__(self, "_n_params", off)
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        object.__setattr__(self, "_bns", bns)
+        object.__setattr__(self, "_bn_hyper", (float(bns[0].momentum), float(bns[0].eps)))
+
+    def __setstate__(self, state):                         # torch.load(full pickle): rebuild bookkeeping
+        super().__setstate__(state)
+        self._init_flat_bookkeeping()
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in ("_flat", "_flat_version", "_last_flat_grad", "_param_slices", "_n_params", "_bns", "_bn_hyper"):
+            state.pop(k, None)
+        return state
+
+    def _is_flat(self, device):
+        f = self._flat
+        if f is None or f[0].device != device:
+            return False
+        fp, fr, fn = f
+        esz = fp.element_size()
+        for p, (o, n, _) in zip(self.parameters(), self._param_slices):
+            if p.device != device or p.dtype != torch.float32 or p.data_ptr() != fp.data_ptr() + o * esz:
+                return False
+        ro = 0
+        for i, bn in enumerate(self._bns):
+            c = bn.num_features
+            if (bn.running_mean.data_ptr() != fr.data_ptr() + ro * 4
+                    or bn.running_var.data_ptr() != fr.data_ptr() + (ro + c) * 4
+                    or bn.num_batches_tracked.data_ptr() != fn.data_ptr() + i * 8):
+                return False
+            ro += 2 * c
+        return True
+
+    def _flat_state(self, device):
+        """Return (flat_params, flat_running, flat_nbt) on ``device``, re-pointing the nn.Parameters /
+        BN buffers into them if something (``.to()``, ``load_state_dict(assign=True)``...) moved them."""
+        if self._is_flat(device):
+            return self._flat
+        params = list(self.parameters())
+        for p in params:
+            if p.device != device:
+                raise _lib.SifsrError(f"model parameters are on {p.device} but the input is on {device}; call model.to(device)")
+        with torch.no_grad():
+            fp = torch.empty(self._n_params, dtype=torch.float32, device=device)
+            for p, (o, n, s) in zip(params, self._param_slices):
+                fp[o:o + n].copy_(p.detach().reshape(-1).float())
+                p.data = fp[o:o + n].view(s)
+            nrun = 2 * sum(bn.num_features for bn in self._bns)
+            fr = torch.empty(nrun, dtype=torch.float32, device=device)
+            fn = torch.empty(len(self._bns), dtype=torch.int64, device=device)
+            ro = 0
+            for i, bn in enumerate(self._bns):
+                c = bn.num_features
+                fr[ro:ro + c].copy_(bn.running_mean)
+                fr[ro + c:ro + 2 * c].copy_(bn.running_var)
+                fn[i] = bn.num_batches_tracked.to(device)
+                bn.running_mean = fr[ro:ro + c]
+                bn.running_var = fr[ro + c:ro + 2 * c]
+                bn.num_batches_tracked = fn[i]
+                ro += 2 * c
+        assert nrun == _lib.call("sifsr_num_running") and self._n_params == _lib.call("sifsr_num_params")
+        object.__setattr__(self, "_flat", (fp, fr, fn))
+        object.__setattr__(self, "_flat_version", self._flat_version + 1)
+        return self._flat
+
+    def flat_parameters(self):
+        """The single contiguous fp32 tensor all parameters alias (after the first GPU forward)."""
+        dev = next(self.parameters()).device
+        return self._flat_state(dev)[0]
+
+    def flat_grad(self):
+        """The contiguous gradient buffer written by the last backward (None before any)."""
+        return self._last_flat_grad
+
+    # ---- forward -----------------------------------------------------------------------------
+    def forward(self, x_lst_ndvi):
+        """model.py:608-645: (B,2,H,W) = cat(lst_up, ndvi) -> (B,1,H,W) super-resolved LST."""
+        if not x_lst_ndvi.is_cuda:
+            raise _lib.SifsrError("ModelB_2 (MI355X build) has no CPU path: move the model and the input to a ROCm device")
+        x = x_lst_ndvi.contiguous().float()
+        return _ModelFn.apply(self, x, *self.parameters())

@@ -1,0 +1,332 @@
+"""GPU parity: every C-ABI operator (include/sifsr_hip.h) against plain PyTorch fp32 CPU math of the
+same op (the oracle's building blocks).  Tolerances are max|a-b| / max|b|; the north-star bar is
+1e-4 relative, fp32."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # BASELINE.json north_star: within 1e-4 relative fp32
+
+
+@pytest.fixture(scope="module")
+def L():
+    import sifsr
+    from sifsr import _lib
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return _lib
+
+
+def dev(t):
+    return t.contiguous().cuda()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def S():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rnd(rs, *shape, scale=1.0):
+    return torch.from_numpy((rs.standard_normal(shape) * scale).astype(np.float32))
+
+
+def conv_rep(x, w, b=None):
+    return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), w, b)
+
+
+# (C0, C1, cout, H, W, B, affine0, affine1)
+CONV_CASES = [
+    (16, 0, 16, 32, 48, 2, True, False),
+    (16, 0, 32, 16, 16, 1, False, False),
+    (32, 0, 32, 32, 32, 2, True, False),
+    (32, 0, 64, 16, 32, 1, True, False),
+    (64, 0, 64, 32, 32, 1, True, False),
+    (64, 64, 64, 32, 32, 1, False, True),    # ub1.convbloc.bloc.0: cat([up, skip])
+    (32, 32, 32, 32, 32, 1, False, True),    # ub2
+    (16, 16, 16, 32, 32, 2, False, True),    # ub3
+    (64, 0, 32, 16, 16, 2, True, False),
+    (32, 0, 16, 32, 16, 1, True, False),
+]
+
+
+def _mk_inputs(rs, C0, C1, B, H, W, aff0, aff1):
+    x0 = rnd(rs, B, C0, H, W)
+    x1 = rnd(rs, B, C1, H, W) if C1 else None
+    sc0 = torch.from_numpy(rs.uniform(0.5, 1.5, C0).astype(np.float32)) if aff0 else None
+    sh0 = rnd(rs, C0, scale=0.3) if aff0 else None
+    sc1 = torch.from_numpy(rs.uniform(0.5, 1.5, C1).astype(np.float32)) if (C1 and aff1) else None
+    sh1 = rnd(rs, C1, scale=0.3) if (C1 and aff1) else None
+
+    def act(x, sc, sh):
+        return F.relu(x * sc[None, :, None, None] + sh[None, :, None, None]) if sc is not None else x
+    a = act(x0, sc0, sh0)
+    if C1:
+        a = torch.cat([a, act(x1, sc1, sh1)], 1)
+    return x0, x1, sc0, sh0, sc1, sh1, a
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_fwd_dgrad_wgrad(L, case):
+    C0, C1, cout, H, W, B, aff0, aff1 = case
+    cin = C0 + C1
+    rs = np.random.RandomState(hash(case) % 2**31)
+    x0, x1, sc0, sh0, sc1, sh1, a = _mk_inputs(rs, C0, C1, B, H, W, aff0, aff1)
+    w = rnd(rs, cout, cin, 3, 3, scale=(2.0 / (9 * cin)) ** 0.5)
+    a = a.requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = conv_rep(a, wr)
+    dy = rnd(rs, B, cout, H, W)
+    ga_ref, gw_ref = torch.autograd.grad((y_ref * dy).sum(), [a, wr])
+
+    dw_, d0 = dev(w), dev(nhwc(x0))
+    d1 = dev(nhwc(x1)) if C1 else None
+    dsc0, dsh0 = (dev(sc0), dev(sh0)) if aff0 else (None, None)
+    dsc1, dsh1 = (dev(sc1), dev(sh1)) if sc1 is not None else (None, None)
+    wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty_like(wf)
+    L.call("sifsr_pack_conv_weights", dw_, cin, cout, wf, wd, S())
+
+    # ---- forward + BN statistic partials ----
+    y = torch.empty(B, H, W, cout, device="cuda")
+    nblk = B * (H // 16) * (W // 16)
+    part = torch.empty(nblk, cout, 2, device="cuda")
+    L.call("sifsr_conv3x3_fwd", d0, C0, dsc0, dsh0, d1, C1, dsc1, dsh1, wf, y, cout, part, B, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(nchw(y.cpu()), y_ref) < TOL
+    ps = part.cpu().double().sum(0)
+    yr = y_ref.detach().double()
+    assert torch.allclose(ps[:, 0], yr.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(ps[:, 1], (yr * yr).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+    # ---- dgrad (incl. replicate border fold), split destinations for the concat case ----
+    ddy = dev(nhwc(dy))
+    g0 = torch.full((B, H, W, C0), float("nan"), device="cuda")
+    g1 = torch.full((B, H, W, C1), float("nan"), device="cuda") if C1 else None
+    L.call("sifsr_conv3x3_dgrad", ddy, cout, wd, dw_, cin, g0, C0, g1, C1, None, B, H, W, S())
+    torch.cuda.synchronize()
+    g = nchw(g0.cpu()) if not C1 else torch.cat([nchw(g0.cpu()), nchw(g1.cpu())], 1)
+    assert rel_err(g, ga_ref) < TOL
+    if not C1:   # residual addend variant
+        add = rnd(rs, B, cin, H, W)
+        g2 = torch.empty(B, H, W, cin, device="cuda")
+        L.call("sifsr_conv3x3_dgrad", ddy, cout, wd, dw_, cin, g2, cin, None, 0, dev(nhwc(add)), B, H, W, S())
+        torch.cuda.synchronize()
+        assert rel_err(nchw(g2.cpu()), ga_ref + add) < TOL
+
+    # ---- wgrad ----
+    for nb in (1, 7, 64):
+        scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_scratch_floats", cin, cout, nb), device="cuda")
+        dwo = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+        L.call("sifsr_conv3x3_wgrad", d0, C0, dsc0, dsh0, d1, C1, dsc1, dsh1, ddy, cout, scratch, nb, dwo, B, H, W, S())
+        torch.cuda.synchronize()
+        assert rel_err(dwo.cpu(), gw_ref) < TOL, nb
+
+
+def test_conv_in(L):
+    rs = np.random.RandomState(1)
+    B, H, W = 2, 32, 48
+    x = rnd(rs, B, 2, H, W)
+    w = rnd(rs, 16, 2, 3, 3, scale=0.3).requires_grad_(True)
+    y_ref = conv_rep(x, w)
+    dy = rnd(rs, B, 16, H, W)
+    (gw_ref,) = torch.autograd.grad((y_ref * dy).sum(), [w])
+    y = torch.empty(B, H, W, 16, device="cuda")
+    nblk = B * (H // 16) * (W // 16)
+    part = torch.empty(nblk, 16, 2, device="cuda")
+    L.call("sifsr_conv_in_fwd", dev(x), dev(w.detach()), y, part, B, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(nchw(y.cpu()), y_ref) < TOL
+    assert torch.allclose(part.cpu().double().sum(0)[:, 0], y_ref.detach().double().sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    scratch = torch.empty(8 * 288, device="cuda")
+    dw = torch.empty(16, 2, 3, 3, device="cuda")
+    L.call("sifsr_conv_in_wgrad", dev(x), dev(nhwc(dy)), scratch, 5, dw, B, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), gw_ref) < TOL
+
+
+def test_conv_out(L):
+    rs = np.random.RandomState(2)
+    B, H, W = 2, 32, 48
+    yraw = rnd(rs, B, 16, H, W)
+    sc = torch.from_numpy(rs.uniform(0.5, 1.5, 16).astype(np.float32)); sh = rnd(rs, 16, scale=0.3)
+    a = F.relu(yraw * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+    w = rnd(rs, 1, 16, 3, 3, scale=0.2).requires_grad_(True)
+    b = rnd(rs, 1).requires_grad_(True)
+    out_ref = conv_rep(a, w, b)
+    dsr = rnd(rs, B, 1, H, W)
+    ga_ref, gw_ref, gb_ref = torch.autograd.grad((out_ref * dsr).sum(), [a, w, b])
+    out = torch.empty(B, 1, H, W, device="cuda")
+    dy_, dsc, dsh, dw_, db_ = dev(nhwc(yraw)), dev(sc), dev(sh), dev(w.detach()), dev(b.detach())
+    L.call("sifsr_conv_out_fwd", dy_, dsc, dsh, dw_, db_, out, B, H, W, S())
+    g = torch.empty(B, H, W, 16, device="cuda")
+    L.call("sifsr_conv_out_dgrad", dev(dsr), dw_, g, B, H, W, S())
+    scratch = torch.empty(8 * 145, device="cuda")
+    dwb = torch.empty(145, device="cuda")
+    L.call("sifsr_conv_out_wgrad", dy_, dsc, dsh, dev(dsr), scratch, 5, dwb, B, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), out_ref) < TOL
+    assert rel_err(nchw(g.cpu()), ga_ref) < TOL
+    assert rel_err(dwb.cpu()[:144].view(1, 16, 3, 3), gw_ref) < TOL
+    assert rel_err(dwb.cpu()[144:], gb_ref) < TOL
+
+
+@pytest.mark.parametrize("C", [16, 32, 64])
+def test_batchnorm_fwd_bwd(L, C):
+    rs = np.random.RandomState(3 + C)
+    B, H, W = 2, 32, 32
+    y = (rnd(rs, B, C, H, W) * 1.7 + 0.4).requires_grad_(True)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)).requires_grad_(True)
+    beta = rnd(rs, C, scale=0.2).requires_grad_(True)
+    rm, rv = rnd(rs, C, scale=0.1), torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32))
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    a_ref = F.relu(F.batch_norm(y, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
+    g = rnd(rs, B, C, H, W)
+    gy_ref, gg_ref, gb_ref = torch.autograd.grad((a_ref * g).sum(), [y, gamma, beta])
+
+    yd = dev(nhwc(y.detach()))
+    # statistics partials as a conv epilogue would produce them (per 16x16 tile)
+    t = y.detach().unfold(2, 16, 16).unfold(3, 16, 16)            # B,C,ty,tx,16,16
+    p1 = t.sum((-1, -2)).permute(0, 2, 3, 1).reshape(-1, C)
+    p2 = (t * t).sum((-1, -2)).permute(0, 2, 3, 1).reshape(-1, C)
+    part = dev(torch.stack([p1, p2], -1))
+    nblk = part.shape[0]
+    drm, drv = dev(rm), dev(rv)
+    mean, invstd, scale, shift = (torch.empty(C, device="cuda") for _ in range(4))
+    L.call("sifsr_bn_finalize", part, nblk, C, float(B * H * W), dev(gamma.detach()), dev(beta.detach()), drm, drv,
+           0.1, 1e-5, mean, invstd, scale, shift, S())
+    torch.cuda.synchronize()
+    assert rel_err(drm.cpu(), rm_ref) < 1e-5 and rel_err(drv.cpu(), rv_ref) < 1e-5
+    a = F.relu(y.detach() * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None])
+    assert rel_err(a, a_ref) < TOL
+
+    npix = B * H * W
+    nb = 8
+    partials = torch.empty(nb * C * 2, device="cuda")
+    dgam, dbet, c1, c0 = (torch.empty(C, device="cuda") for _ in range(4))
+    dy = torch.empty(B, H, W, C, device="cuda")
+    L.call("sifsr_bn_relu_bwd", dev(nhwc(g)), yd, scale, shift, mean, invstd, C, npix, partials, nb, dgam, dbet, c1, c0, dy, S())
+    torch.cuda.synchronize()
+    assert rel_err(dgam.cpu(), gg_ref) < TOL and rel_err(dbet.cpu(), gb_ref) < TOL
+    assert rel_err(nchw(dy.cpu()), gy_ref) < TOL
+
+
+@pytest.mark.parametrize("C", [16, 64])
+def test_resample(L, C):
+    rs = np.random.RandomState(4 + C)
+    B, H, W = 2, 16, 24
+    yraw = rnd(rs, B, C, H, W)
+    sc = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)); sh = rnd(rs, C, scale=0.3)
+    a = F.relu(yraw * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+    yd, dsc, dsh = dev(nhwc(yraw)), dev(sc), dev(sh)
+
+    # avg pool
+    p_ref = F.avg_pool2d(a, 2, 2)
+    gp = rnd(rs, *p_ref.shape)
+    (ga_ref,) = torch.autograd.grad((p_ref * gp).sum(), [a])
+    p = torch.empty(B, H // 2, W // 2, C, device="cuda")
+    L.call("sifsr_bnrelu_pool2", yd, dsc, dsh, p, B, H, W, C, S())
+    base = rnd(rs, B, C, H, W)
+    gacc = dev(nhwc(base))
+    L.call("sifsr_pool2_bwd", dev(nhwc(gp)), gacc, B, H, W, C, 1, S())
+    torch.cuda.synchronize()
+    assert rel_err(nchw(p.cpu()), p_ref) < TOL
+    assert rel_err(nchw(gacc.cpu()), base + ga_ref) < TOL
+
+    # residual add
+    pp = rnd(rs, B, C, H, W)
+    r = torch.empty(B, H, W, C, device="cuda")
+    L.call("sifsr_bnrelu_add", dev(nhwc(pp)), yd, dsc, dsh, r, C, B * H * W, S())
+    torch.cuda.synchronize()
+    assert rel_err(nchw(r.cpu()), pp + a.detach()) < TOL
+
+    # bilinear x2, align_corners=True
+    u_ref = F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=True)
+    gu = rnd(rs, *u_ref.shape)
+    (ga2_ref,) = torch.autograd.grad((u_ref * gu).sum(), [a])
+    u = torch.empty(B, 2 * H, 2 * W, C, device="cuda")
+    L.call("sifsr_bnrelu_up2x", yd, dsc, dsh, u, B, H, W, C, S())
+    g = torch.empty(B, H, W, C, device="cuda")
+    L.call("sifsr_up2x_bwd", dev(nhwc(gu)), g, B, H, W, C, S())
+    torch.cuda.synchronize()
+    assert rel_err(nchw(u.cpu()), u_ref) < TOL
+    assert rel_err(nchw(g.cpu()), ga2_ref) < TOL
+
+
+@pytest.mark.parametrize("hw", [(256, 256), (64, 128)])
+def test_loss_operators(L, hw):
+    import sifsr
+    from oracle import sif_oracle as O
+    H, W = hw
+    rs = np.random.RandomState(5)
+    x = rnd(rs, 2, 1, H, W)
+    xk = x * 5.5698 + 307.2378
+    for name, fo, fh, inp in (
+            ("downscale", O.downscale_LST_SR_to_LR, sifsr.downscale_LST_SR_to_LR, xk),
+            ("ftm", lambda t: O.get_output_ftm(t, mtf=0.25), lambda t: sifsr.get_output_ftm(t, mtf=0.25), x),
+            ("sobel", O.sobel_bank, sifsr.sobel_bank, x)):
+        a = inp.clone().requires_grad_(True)
+        yo = fo(a)
+        wgt = rnd(rs, *yo.shape)
+        (go,) = torch.autograd.grad((yo * wgt).sum(), a)
+        b = inp.clone().cuda().requires_grad_(True)
+        yh = fh(b)
+        (gh,) = torch.autograd.grad((yh * wgt.cuda()).sum(), b)
+        assert rel_err(yh, yo) < TOL, name
+        assert rel_err(gh, go) < TOL, name
+    # huber
+    a = (rnd(rs, 2, 4, 32, 32) * 1.5).requires_grad_(True)
+    t = rnd(rs, 2, 4, 32, 32)
+    lo = O.huber(a, -0.4 * t)
+    (go,) = torch.autograd.grad(lo * 1.7, a)
+    ad = a.detach().cuda().requires_grad_(True)
+    lh = sifsr.huber_loss(ad, t.cuda(), -0.4)
+    (gh,) = torch.autograd.grad(lh * 1.7, ad)
+    assert abs(float(lh) - float(lo)) < TOL * abs(float(lo))
+    assert rel_err(gh, go) < TOL
+
+
+@pytest.mark.parametrize("kind,alpha,gamma", [("sr2", 0.5, -0.25), ("sr1", 0.99, -0.5), ("sr2", 0.1, -0.4)])
+def test_fused_sif_loss(L, kind, alpha, gamma):
+    import sifsr
+    from oracle import sif_oracle as O
+    rs = np.random.RandomState(6)
+    B, H, W = 2, 256, 256
+    sr = (rnd(rs, B, 1, H, W) * 1.3).requires_grad_(True)     # |e| > 1 on a fraction: both Huber branches
+    lst = rnd(rs, B, 1, H // 4, W // 4)
+    ndvi = rnd(rs, B, 1, H, W).clamp(-3, 3)
+    mean, std = 307.2378, 5.5698
+    ds_o, pl_o, loss_o = O.LOSSES[kind](sr, lst, ndvi, mean, std, alpha, gamma)
+    (g_o,) = torch.autograd.grad(loss_o, sr)
+    srd = sr.detach().cuda().requires_grad_(True)
+    ds, pl, loss = sifsr.sif_loss(kind, srd, lst.cuda(), ndvi.cuda(), mean, std, alpha, gamma)
+    (g,) = torch.autograd.grad(loss, srd)
+    for got, ref in ((ds, ds_o), (pl, pl_o), (loss, loss_o)):
+        assert abs(float(got) - float(ref)) < TOL * abs(float(ref)), (kind, float(got), float(ref))
+    assert rel_err(g, g_o) < TOL
+
+
+def test_adam_flat(L):
+    from oracle import sif_oracle as O
+    rs = np.random.RandomState(7)
+    n = 10007
+    p0 = rnd(rs, n)
+    sd = {"p": p0.clone()}
+    adam = O.AdamState(["p"], 1e-3)
+    p = p0.clone().cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        g = rnd(rs, n, scale=0.01)
+        adam.step(sd, {"p": g})
+        L.call("sifsr_adam_flat", p, dev(g * 4), m, v, n, 1e-3, 0.9, 0.999, 1e-8, 0.0, step, 0.25, S())
+    torch.cuda.synchronize()
+    assert rel_err(p.cpu(), sd["p"]) < 1e-6
+    assert rel_err(p.cpu() - p0, sd["p"] - p0) < 1e-4
