@@ -36,6 +36,10 @@ SIFSR_API int sifsr_layer_table(int* out, int capacity_rows);
 
 /* ---- ModelB_2 (model.py:533-645) ------------------------------------------------------------ */
 SIFSR_API size_t sifsr_model_workspace_bytes(int B, int H, int W, int training);
+/* Debug/test introspection: float offsets of the named workspace regions, in this order:
+ * y[17] (raw conv outputs, NHWC), P[3], R[3], U[3], g[17] (dL/d relu(bn(y)) -> overwritten by dL/dy), dyB[3], gP[3], gU[3],
+ * mean, invstd, scale, shift (per-channel vectors of all layers, indexed by ch_off).  Returns the count (56). */
+SIFSR_API int sifsr_model_workspace_regions(int B, int H, int W, size_t* out, int capacity);
 /* ModelB_2.forward, model.py:608-645.  training != 0: batch statistics, running-stat update
  * (momentum, unbiased var) and nbt += 1, activations kept in `workspace` for sifsr_model_backward;
  * training == 0: model.eval() semantics (running statistics), predict.py:68,100. */
@@ -81,10 +85,10 @@ SIFSR_API int sifsr_conv_out_wgrad(const float* y, const float* scale, const flo
 SIFSR_API int sifsr_bn_finalize(const float* stat_partials, int nblk, int C, double count, const float* gamma,
                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                 float* mean, float* invstd, float* scale, float* shift, void* stream);
-/* g = dL/d relu(bn(y)) -> dgamma, dbeta, dy = dL/dy; partials: >= nblk*C*2 floats; c1,c0: C floats scratch */
+/* g = dL/d relu(bn(y)) -> dgamma, dbeta, dy = dL/dy; partials: >= nblk*C*2 floats; coef: 3*C float64 scratch */
 SIFSR_API int sifsr_bn_relu_bwd(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
                                 const float* invstd, int C, size_t npix, float* partials, int nblk, float* dgamma,
-                                float* dbeta, float* c1, float* c0, float* dy, void* stream);
+                                float* dbeta, double* coef, float* dy, void* stream);
 
 /* ---- resampling (NHWC; scale == NULL: input used as stored) ---------------------------------- */
 SIFSR_API int sifsr_bnrelu_pool2(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W, int C, void* stream); /* AvgPool2d(2,2), model.py:504 */

@@ -69,10 +69,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             float* __restrict__ partials) {
   constexpr int Q = C / 4;          // channel quads
   constexpr int PP = 256 / Q;       // pixels per pass per workgroup
-  __shared__ float red[256][8];
+  __shared__ double red[256][8];   // float64 accumulation: dy = scale*(dz - mean(dz) - ...) cancels heavily
   const int tid = threadIdx.x, c4 = tid % Q, pl = tid / Q;
   const float4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4), mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4);
-  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
   for (size_t p = (size_t)blockIdx.x * PP + pl; p < npix; p += (size_t)gridDim.x * PP) {
     const float4 yv = ld4(y + p * C + 4 * c4), gv = ld4(g + p * C + 4 * c4);
     const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float dz = fmaf(yy[j], scv[j], shv[j]) > 0.f ? gg[j] : 0.f;
-      a1[j] += dz;
-      a2[j] = fmaf(dz, (yy[j] - muv[j]) * isv[j], a2[j]);
+      a1[j] += (double)dz;
+      a2[j] += (double)dz * (double)((yy[j] - muv[j]) * isv[j]);
     }
   }
 #pragma unroll
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   if (pl == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      partials[((size_t)blockIdx.x * C + 4 * c4 + j) * 2 + 0] = red[tid][j];
-      partials[((size_t)blockIdx.x * C + 4 * c4 + j) * 2 + 1] = red[tid][4 + j];
+      partials[((size_t)blockIdx.x * C + 4 * c4 + j) * 2 + 0] = (float)red[tid][j];
+      partials[((size_t)blockIdx.x * C + 4 * c4 + j) * 2 + 1] = (float)red[tid][4 + j];
     }
   }
 }
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               double count, const float* __restrict__ scale,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* dgamma,
-                                                              float* dbeta, float* c1, float* c0) {
+                                                              float* dbeta, double* coef) {
   __shared__ double r1[256], r2[256];
   const int c = blockIdx.x, tid = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
@@ -127,9 +127,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     const double db = r1[0], dg = r2[0];
     dbeta[c] = (float)db;
     dgamma[c] = (float)dg;
+    // dy = scale*dz + k1*y + k0, kept in float64: the three terms cancel to << |scale*dz| when the
+    // incoming gradient is smooth (ATen's CPU kernel also evaluates this in acc_type<float> = double)
     const double k1 = -(double)scale[c] * (double)invstd[c] * dg / count;
-    c1[c] = (float)k1;
-    c0[c] = (float)(-(double)scale[c] * db / count - k1 * (double)mean[c]);
+    coef[c] = (double)scale[c];
+    coef[C + c] = k1;
+    coef[2 * C + c] = -(double)scale[c] * db / count - k1 * (double)mean[c];
   }
 }
 
@@ -137,18 +140,21 @@ template <int C>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
-                                                           const float* __restrict__ c1, const float* __restrict__ c0,
+                                                           const double* __restrict__ coef,
                                                            size_t nquads, float* __restrict__ dy) {
   constexpr int Q = C / 4;
   const int c4 = threadIdx.x % Q;   // 256 % Q == 0 and grid stride is a multiple of 256
-  const float4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4), k1 = ld4(c1 + 4 * c4), k0 = ld4(c0 + 4 * c4);
+  const float4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4);
+  double sd[4], k1[4], k0[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sd[j] = coef[4 * c4 + j]; k1[j] = coef[C + 4 * c4 + j]; k0[j] = coef[2 * C + 4 * c4 + j]; }
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nquads; e += (size_t)gridDim.x * 256) {
     const float4 yv = ld4(y + e * 4), gv = ld4(g + e * 4);
     float4 o;
-    o.x = fmaf(sc.x, fmaf(yv.x, sc.x, sh.x) > 0.f ? gv.x : 0.f, fmaf(k1.x, yv.x, k0.x));
-    o.y = fmaf(sc.y, fmaf(yv.y, sc.y, sh.y) > 0.f ? gv.y : 0.f, fmaf(k1.y, yv.y, k0.y));
-    o.z = fmaf(sc.z, fmaf(yv.z, sc.z, sh.z) > 0.f ? gv.z : 0.f, fmaf(k1.z, yv.z, k0.z));
-    o.w = fmaf(sc.w, fmaf(yv.w, sc.w, sh.w) > 0.f ? gv.w : 0.f, fmaf(k1.w, yv.w, k0.w));
+    o.x = (float)fma(sd[0], (double)(fmaf(yv.x, sc.x, sh.x) > 0.f ? gv.x : 0.f), fma(k1[0], (double)yv.x, k0[0]));
+    o.y = (float)fma(sd[1], (double)(fmaf(yv.y, sc.y, sh.y) > 0.f ? gv.y : 0.f), fma(k1[1], (double)yv.y, k0[1]));
+    o.z = (float)fma(sd[2], (double)(fmaf(yv.z, sc.z, sh.z) > 0.f ? gv.z : 0.f), fma(k1[2], (double)yv.z, k0[2]));
+    o.w = (float)fma(sd[3], (double)(fmaf(yv.w, sc.w, sh.w) > 0.f ? gv.w : 0.f), fma(k1[3], (double)yv.w, k0[3]));
     st4(dy + e * 4, o);
   }
 }
@@ -194,22 +200,22 @@ int launch_bn_bwd_reduce(const float* g, const float* y, const float* scale, con
 }
 
 int launch_bn_bwd_finalize(const float* partials, int nblk, int C, double count, const float* scale, const float* mean,
-                           const float* invstd, float* dgamma, float* dbeta, float* c1, float* c0, hipStream_t s) {
+                           const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, partials, nblk, C, count, scale, mean, invstd,
-                     dgamma, dbeta, c1, c0);
+                     dgamma, dbeta, coef);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
 
-int launch_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, const float* c1,
-                        const float* c0, int C, size_t npix, float* dy, hipStream_t s) {
+int launch_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, const double* coef,
+                        int C, size_t npix, float* dy, hipStream_t s) {
   const size_t nquads = npix * (size_t)C / 4;
   size_t blocks = (nquads + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   switch (C) {
-    case 16: hipLaunchKernelGGL((bn_bwd_apply_kernel<16>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, c1, c0, nquads, dy); break;
-    case 32: hipLaunchKernelGGL((bn_bwd_apply_kernel<32>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, c1, c0, nquads, dy); break;
-    case 64: hipLaunchKernelGGL((bn_bwd_apply_kernel<64>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, c1, c0, nquads, dy); break;
+    case 16: hipLaunchKernelGGL((bn_bwd_apply_kernel<16>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, coef, nquads, dy); break;
+    case 32: hipLaunchKernelGGL((bn_bwd_apply_kernel<32>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, coef, nquads, dy); break;
+    case 64: hipLaunchKernelGGL((bn_bwd_apply_kernel<64>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, coef, nquads, dy); break;
     default: return SIFSR_ERR_SHAPE;
   }
   SIFSR_LAUNCH_CHECK();

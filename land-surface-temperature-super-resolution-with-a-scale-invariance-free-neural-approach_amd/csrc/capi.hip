@@ -28,6 +28,22 @@ size_t sifsr_model_workspace_bytes(int B, int H, int W, int training) {
   if (sifsr_layout(B, H, W, training, &l) != SIFSR_OK) return 0;
   return l.total * sizeof(float);
 }
+int sifsr_model_workspace_regions(int B, int H, int W, size_t* out, int capacity) {
+  WsLayout l;
+  if (sifsr_layout(B, H, W, 1, &l) != SIFSR_OK) return 0;
+  size_t v[56]; int n = 0;
+  for (int i = 0; i < 17; ++i) v[n++] = l.y[i];
+  for (int i = 0; i < 3; ++i) v[n++] = l.P[i];
+  for (int i = 0; i < 3; ++i) v[n++] = l.R[i];
+  for (int i = 0; i < 3; ++i) v[n++] = l.U[i];
+  for (int i = 0; i < 17; ++i) v[n++] = l.g[i];
+  for (int i = 0; i < 3; ++i) v[n++] = l.dyB[i];
+  for (int i = 0; i < 3; ++i) v[n++] = l.gP[i];
+  for (int i = 0; i < 3; ++i) v[n++] = l.gU[i];
+  v[n++] = l.mean; v[n++] = l.invstd; v[n++] = l.scale; v[n++] = l.shift;
+  for (int i = 0; i < n && i < capacity; ++i) out[i] = v[i];
+  return n;
+}
 int sifsr_model_forward(const float* x, float* sr, const float* params, float* running, long long* nbt, void* workspace,
                         size_t workspace_bytes, int B, int H, int W, int training, float momentum, float eps, void* stream) {
   return sifsr_engine_forward(x, sr, params, running, nbt, (float*)workspace, workspace_bytes / sizeof(float), B, H, W,
@@ -117,12 +133,12 @@ int sifsr_bn_finalize(const float* stat_partials, int nblk, int C, double count,
 }
 int sifsr_bn_relu_bwd(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
                       const float* invstd, int C, size_t npix, float* partials, int nblk, float* dgamma, float* dbeta,
-                      float* c1, float* c0, float* dy, void* stream) {
+                      double* coef, float* dy, void* stream) {
   int rc = launch_bn_bwd_reduce(g, y, scale, shift, mean, invstd, C, npix, partials, nblk, S(stream));
   if (rc) return rc;
-  rc = launch_bn_bwd_finalize(partials, nblk, C, (double)npix, scale, mean, invstd, dgamma, dbeta, c1, c0, S(stream));
+  rc = launch_bn_bwd_finalize(partials, nblk, C, (double)npix, scale, mean, invstd, dgamma, dbeta, coef, S(stream));
   if (rc) return rc;
-  return launch_bn_bwd_apply(g, y, scale, shift, c1, c0, C, npix, dy, S(stream));
+  return launch_bn_bwd_apply(g, y, scale, shift, coef, C, npix, dy, S(stream));
 }
 
 int sifsr_bnrelu_pool2(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W, int C, void* stream) {

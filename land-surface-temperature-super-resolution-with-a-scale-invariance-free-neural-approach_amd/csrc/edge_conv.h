@@ -23,9 +23,9 @@ int launch_bn_eval_coeffs(const float* params, const float* running, float eps, 
 int launch_bn_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
                          const float* invstd, int C, size_t npix, float* partials, int nblk, hipStream_t s);
 int launch_bn_bwd_finalize(const float* partials, int nblk, int C, double count, const float* scale, const float* mean,
-                           const float* invstd, float* dgamma, float* dbeta, float* c1, float* c0, hipStream_t s);
-int launch_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, const float* c1,
-                        const float* c0, int C, size_t npix, float* dy, hipStream_t s);
+                           const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s);
+int launch_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, const double* coef,
+                        int C, size_t npix, float* dy, hipStream_t s);
 int launch_nbt_increment(long long* nbt, int n, hipStream_t s);
 
 // ---- resample.hip ---- (all NHWC, C % 4 == 0; scale == nullptr => input used as stored)

@@ -14,7 +14,7 @@ struct WsLayout {
   size_t P[3], R[3], U[3];                // pooled inputs, residual sums, upsampled decoder inputs
   size_t partials;                        // BN statistic partials (scratch)
   size_t fwd_end;
-  size_t c1, c0;                          // BN-backward affine coefficients
+  size_t coef;                            // BN-backward affine coefficients (3 x C float64, current layer)
   size_t g[SIFSR_NUM_BN_LAYERS];          // grad w.r.t. relu(bn(y_l)), overwritten in place by dy_l
   size_t dyB[3];                          // dy of the residual blocks' second conv
   size_t gP[3], gU[3];

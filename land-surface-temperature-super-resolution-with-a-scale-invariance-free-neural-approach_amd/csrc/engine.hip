@@ -83,7 +83,7 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
   w.partials = take(maxpart);
   w.fwd_end = off;
   if (training) {
-    w.c1 = take(nt.total_channels); w.c0 = take(nt.total_channels);
+    w.coef = take(6 * 64);   // 3 x C float64 BN-backward coefficients of the layer being processed
     for (int l = 0; l < SIFSR_NUM_BN_LAYERS; ++l) w.g[l] = take(nt.L[l].cout * N[nt.L[l].level]);
     w.dyB[0] = take(16 * N[1]); w.dyB[1] = take(32 * N[2]); w.dyB[2] = take(64 * N[3]);
     for (int k = 0; k < 3; ++k) w.gP[k] = take(pc[k] * N[k + 1]);
@@ -162,8 +162,8 @@ int bn_unit_bwd(const Ctx& c, int l, const float* g, float* dy, float* grads) {
                                  L.cout, npix, c.f(c.lay.partials), nblk, c.s));
   SIFSR_TRY(launch_bn_bwd_finalize(c.f(c.lay.partials), nblk, L.cout, (double)npix, c.scale(l), c.f(c.lay.mean) + L.ch_off,
                                    c.f(c.lay.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
-                                   c.f(c.lay.c1) + L.ch_off, c.f(c.lay.c0) + L.ch_off, c.s));
-  SIFSR_TRY(launch_bn_bwd_apply(g, y, c.scale(l), c.shift(l), c.f(c.lay.c1) + L.ch_off, c.f(c.lay.c0) + L.ch_off, L.cout,
+                                   reinterpret_cast<double*>(c.f(c.lay.coef)), c.s));
+  SIFSR_TRY(launch_bn_bwd_apply(g, y, c.scale(l), c.shift(l), reinterpret_cast<const double*>(c.f(c.lay.coef)), L.cout,
                                 npix, dy, c.s));
   return SIFSR_OK;
 }

@@ -212,9 +212,10 @@ def test_batchnorm_fwd_bwd(L, C):
     npix = B * H * W
     nb = 8
     partials = torch.empty(nb * C * 2, device="cuda")
-    dgam, dbet, c1, c0 = (torch.empty(C, device="cuda") for _ in range(4))
+    dgam, dbet = (torch.empty(C, device="cuda") for _ in range(2))
+    coef = torch.empty(3 * C, dtype=torch.float64, device="cuda")
     dy = torch.empty(B, H, W, C, device="cuda")
-    L.call("sifsr_bn_relu_bwd", dev(nhwc(g)), yd, scale, shift, mean, invstd, C, npix, partials, nb, dgam, dbet, c1, c0, dy, S())
+    L.call("sifsr_bn_relu_bwd", dev(nhwc(g)), yd, scale, shift, mean, invstd, C, npix, partials, nb, dgam, dbet, coef, dy, S())
     torch.cuda.synchronize()
     assert rel_err(dgam.cpu(), gg_ref) < TOL and rel_err(dbet.cpu(), gb_ref) < TOL
     assert rel_err(nchw(dy.cpu()), gy_ref) < TOL
