@@ -122,4 +122,11 @@ SIFSR_API int sifsr_adam_flat(float* params, const float* grads, float* exp_avg,
                               float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                               void* stream);
 
+/* ---- measurement hook (bench.py roofline) ------------------------------------------------------
+ * Time ONE kernel of the model schedule with HIP events on its launch stream, inside normal steps:
+ * layer = row of sifsr_layer_table, phase 1 = forward conv, 2 = dgrad, 3 = wgrad; layer < 0 disables.
+ * sifsr_profile_read synchronises the recorded events and returns their summed duration and count. */
+SIFSR_API int sifsr_profile_select(int layer, int phase);
+SIFSR_API int sifsr_profile_read(float* total_ms, int* count);
+
 #endif /* SIFSR_HIP_H */

@@ -83,9 +83,8 @@ int sifsr_conv3x3_dgrad(const float* dy, int cout, const float* wdgrad, const fl
   a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
   a.wpack = wdgrad; a.addend = addend; a.addC = cin; a.stat_partials = nullptr; a.dst_split = C0 / 16;
   a.B = B; a.H = H; a.W = W; a.NQ = cout / 16;
-  int rc = launch_conv3x3_mfma(a, cin, 1, S(stream));
-  if (rc) return rc;
-  return launch_dgrad_border_fix(dy, cout, w_oihw, cin, g0, C0, 0, C0, g1 ? g1 : g0, g1 ? C1 : C0, 0, B, H, W, S(stream));
+  (void)w_oihw;   // kept in the signature for ABI stability; the border fold now uses the packed weights
+  return launch_conv3x3_mfma(a, cin, 1, S(stream));
 }
 
 size_t sifsr_conv3x3_wgrad_scratch_floats(int cin, int cout, int nblk) { return (size_t)nblk * wgrad_slab_floats(cin, cout); }
@@ -191,3 +190,6 @@ int sifsr_adam_flat(float* params, const float* grads, float* exp_avg, float* ex
                     float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
   return launch_adam_flat(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S(stream));
 }
+
+int sifsr_profile_select(int layer, int phase) { return sifsr_engine_profile_select(layer, phase); }
+int sifsr_profile_read(float* total_ms, int* count) { return sifsr_engine_profile_read(total_ms, count); }

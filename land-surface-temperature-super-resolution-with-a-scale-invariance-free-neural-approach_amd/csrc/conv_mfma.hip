@@ -1,7 +1,8 @@
 // 3x3 convolution (stride 1) as an implicit GEMM on the fp32 matrix cores of gfx950.
 //
 // Replaces what the reference dispatches to ATen/MKLDNN/cuDNN for nn.Conv2d(k=3, padding=1,
-// padding_mode='replicate', bias=False) -- model.py:135,138,507 -- and its input-gradient.
+// padding_mode='replicate', bias=False) -- model.py:135,138,507 -- and its input-gradient (the
+// replicate-padding adjoint is folded in as extra masked taps on image-border tiles).
 //
 // Mapping (one workgroup = 256 threads = 4 waves, one 16x16-pixel output tile of one image):
 //   * the (16+2)x(16+2) input halo tile of one 16-channel block is staged in LDS as
@@ -108,6 +109,12 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
     if (q + 1 < NQ) issue_loads(q + 1);   // in flight while this block is multiplied
 
     const int kq = lane >> 4, px = lane & 15;
+    auto mac4 = [&](f32x4& d, const float4& w, const float4& bv) {
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, bv.x, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, bv.y, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, bv.z, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, bv.w, d, 0, 0, 0);
+    };
 #pragma unroll
     for (int gb = 0; gb < NG / 4; ++gb) {
 #pragma unroll
@@ -134,6 +141,59 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
 #pragma unroll
           for (int gi = 0; gi < 4; ++gi)
             acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, bf[gi].w, acc[c][gb * 4 + gi], 0, 0, 0);
+        }
+      }
+      if (ZERO_PAD && (x0 == 0 || x0 + 16 == W)) {
+        // Replicate-padding adjoint, x direction.  The forward read x[clamp(p+t)]; the gradient of the
+        // clamped reads returns to the border column:  g[q] += W^T_(ty, tx=-1) dy[q - (ty,0)] for qx = 0
+        // and the mirror image for qx = W-1.  In this kernel's correlation form (weights pre-flipped) that
+        // is tap (ty, 2) resp. (ty, 0) applied to the CENTRE column, on the border lanes only.
+        const bool lf = x0 == 0 && px == 0, rt = x0 + 16 == W && px == 15;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi) {
+            const int r = g0 + gb * 4 + gi;
+            const float4 cv = lds[kq * PLANE + (r + ty) * PW + 1 + px];
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < CBW; ++c) {
+              if (x0 == 0) mac4(acc[c][gb * 4 + gi], wf[c][ty * 3 + 2], lf ? cv : z4);
+              if (x0 + 16 == W) mac4(acc[c][gb * 4 + gi], wf[c][ty * 3 + 0], rt ? cv : z4);
+            }
+          }
+      }
+    }
+    if (ZERO_PAD) {
+      // y direction (and the corners): tile row 0 of an image-top tile / row 15 of an image-bottom tile.
+      const bool lf = x0 == 0 && px == 0, rt = x0 + 16 == W && px == 15;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (y0 == 0 && g0 == 0) {
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const float4 bv = lds[kq * PLANE + 1 * PW + tx + px];
+#pragma unroll
+          for (int c = 0; c < CBW; ++c) mac4(acc[c][0], wf[c][6 + tx], bv);
+        }
+        const float4 cv = lds[kq * PLANE + 1 * PW + 1 + px];
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) {
+          if (x0 == 0) mac4(acc[c][0], wf[c][8], lf ? cv : z4);
+          if (x0 + 16 == W) mac4(acc[c][0], wf[c][6], rt ? cv : z4);
+        }
+      }
+      if (y0 + 16 == H && g0 + NG == 16) {
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const float4 bv = lds[kq * PLANE + 16 * PW + tx + px];
+#pragma unroll
+          for (int c = 0; c < CBW; ++c) mac4(acc[c][NG - 1], wf[c][tx], bv);
+        }
+        const float4 cv = lds[kq * PLANE + 16 * PW + 1 + px];
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) {
+          if (x0 == 0) mac4(acc[c][NG - 1], wf[c][2], lf ? cv : z4);
+          if (x0 + 16 == W) mac4(acc[c][NG - 1], wf[c][0], rt ? cv : z4);
         }
       }
     }
@@ -225,55 +285,6 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// dgrad border fold.  Forward reads x[clamp(p + t)] (replicate padding); its adjoint sends the
-// gradient of every out-of-range read back to the clamped pixel:
-//   g[q] = sum_t W_t^T * sum_{p : clamp(p+t) = q} dy[p]
-// The MFMA kernel (zero_pad) already added the p = q - t terms; this kernel adds the rest, which is
-// non-empty only for q on the image border.  Per axis the extra source exists only for
-// (q = 0, t = -1) -> p = 0 and (q = N-1, t = +1) -> p = N-1.
-// One thread per (border pixel, input channel).
-// ---------------------------------------------------------------------------------------------
-__global__ void dgrad_border_fix_kernel(const float* __restrict__ dy, int Cout, const float* __restrict__ Wt,
-                                        int Cin, float* g0, int C0, int coff0, int split_ch, float* g1,
-                                        int C1, int coff1, int B, int H, int W) {
-  const int per_img = 2 * W + 2 * (H - 2);
-  const int total = B * per_img * Cin;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int ci = e % Cin;
-    const int bp = (e / Cin) % per_img;
-    const int b = e / (Cin * per_img);
-    int qy, qx;
-    if (bp < W) { qy = 0; qx = bp; }
-    else if (bp < 2 * W) { qy = H - 1; qx = bp - W; }
-    else { const int r = bp - 2 * W; qy = 1 + (r >> 1); qx = (r & 1) ? W - 1 : 0; }
-    float acc = 0.f;
-    for (int ty = -1; ty <= 1; ++ty) {
-      // candidate source rows for this tap: base (qy - ty) and the clamped extra
-      int ys[2], ny = 0; bool ybase[2];
-      if (qy - ty >= 0 && qy - ty < H) { ys[ny] = qy - ty; ybase[ny++] = true; }
-      if ((qy == 0 && ty == -1) || (qy == H - 1 && ty == 1)) { ys[ny] = qy; ybase[ny++] = false; }
-      for (int tx = -1; tx <= 1; ++tx) {
-        int xs[2], nx = 0; bool xbase[2];
-        if (qx - tx >= 0 && qx - tx < W) { xs[nx] = qx - tx; xbase[nx++] = true; }
-        if ((qx == 0 && tx == -1) || (qx == W - 1 && tx == 1)) { xs[nx] = qx; xbase[nx++] = false; }
-        const int tap = (ty + 1) * 3 + (tx + 1);
-        for (int iy = 0; iy < ny; ++iy)
-          for (int ix = 0; ix < nx; ++ix) {
-            if (ybase[iy] && xbase[ix]) continue;   // already done by the MFMA kernel
-            const float* d = dy + ((size_t)(b * H + ys[iy]) * W + xs[ix]) * Cout;
-            float s = 0.f;
-            for (int co = 0; co < Cout; ++co) s = fmaf(Wt[(co * Cin + ci) * 9 + tap], d[co], s);
-            acc += s;
-          }
-      }
-    }
-    const size_t pix = (size_t)(b * H + qy) * W + qx;
-    if (ci < split_ch) g0[pix * C0 + coff0 + ci] += acc;
-    else g1[pix * C1 + coff1 + ci - split_ch] += acc;
-  }
-}
-
 }  // namespace
 
 int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s) {
@@ -322,18 +333,6 @@ int launch_pack_weights_one(const float* w, int cin, int cout, float* wfwd, floa
   const int n = 9 * cin * cout;
   const dim3 grid((n + 255) / 256 > 64 ? 64 : (n + 255) / 256, 1);
   hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, s, w, wfwd, wdg, tb);
-  SIFSR_LAUNCH_CHECK();
-  return SIFSR_OK;
-}
-
-int launch_dgrad_border_fix(const float* dy, int Cout, const float* w_oihw, int Cin, float* g0, int C0,
-                            int coff0, int split_ch, float* g1, int C1, int coff1, int B, int H, int W,
-                            hipStream_t s) {
-  const int total = B * (2 * W + 2 * (H - 2)) * Cin;
-  int blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(dgrad_border_fix_kernel, dim3(blocks), dim3(256), 0, s, dy, Cout, w_oihw, Cin, g0, C0,
-                     coff0, split_ch, g1, C1, coff1, B, H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

@@ -148,21 +148,30 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
 
 // dW[co][ci][t] = sum over workgroups of slab[blk][chunk][nbo][nbi][t][lane][r]
 //   co = 16 nbo + 4 (lane>>4) + r,  ci = 16 (chunk*NBI + nbi) + (lane & 15)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int nblk, int cin, int cout, int nbi_chunk,
-                                    float* __restrict__ dw) {
+// One thread per slab element j (so every pass over the slabs is a coalesced stream), 8 slab groups
+// per element reduced through LDS in a fixed order, scattered once to the OIHW gradient.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nblk, int cin, int cout,
+                                                           int nbi_chunk, float* __restrict__ dw) {
+  __shared__ double part[8][32];
   const int n = 9 * cin * cout;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const int t = e % 9, ci = (e / 9) % cin, co = e / (9 * cin);
-  const int nbo = co >> 4, lane = ((co & 15) >> 2) * 16 + (ci & 15), r = co & 3;
-  const int qi = ci >> 4, chunk = qi / nbi_chunk, nbi = qi % nbi_chunk;
-  const int NBO = cout / 16;
-  const size_t per_chunk = (size_t)NBO * nbi_chunk * 9 * 256;
-  const size_t slab_floats = (size_t)n;   // == chunks * per_chunk
-  const float* p = slabs + chunk * per_chunk + ((size_t)((nbo * nbi_chunk + nbi) * 9 + t)) * 256 + lane * 4 + r;
+  const int jl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + jl;
   double s = 0.0;
-  for (int k = 0; k < nblk; ++k) s += (double)p[(size_t)k * slab_floats];
-  dw[e] = (float)s;
+  if (j < n)
+    for (int k = grp; k < nblk; k += 8) s += (double)slabs[(size_t)k * n + j];
+  part[grp][jl] = s;
+  __syncthreads();
+  if (grp == 0 && j < n) {
+    for (int g = 1; g < 8; ++g) s += part[g][jl];
+    const int r = j & 3, lane = (j >> 2) & 63;
+    const int rest = j >> 8;
+    const int t = rest % 9, r2 = rest / 9;
+    const int NBO = cout / 16;
+    const int nbi = r2 % nbi_chunk, r3 = r2 / nbi_chunk;
+    const int nbo = r3 % NBO, chunk = r3 / NBO;
+    const int co = 16 * nbo + 4 * (lane >> 4) + r, ci = 16 * (chunk * nbi_chunk + nbi) + (lane & 15);
+    dw[(co * cin + ci) * 9 + t] = (float)s;
+  }
 }
 
 template <int NBO, int NBI>
@@ -189,7 +198,7 @@ int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStr
 
 int launch_wgrad_reduce(const float* slabs, int nblk, int cin, int cout, float* dw_oihw, hipStream_t s) {
   const int n = 9 * cin * cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, slabs, nblk, cin, cout,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, slabs, nblk, cin, cout,
                      wgrad_nbi_chunk(cin), dw_oihw);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;

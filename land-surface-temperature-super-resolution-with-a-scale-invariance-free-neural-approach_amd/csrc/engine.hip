@@ -12,6 +12,8 @@
 
 #include <stdio.h>
 
+#include <vector>
+
 // ---------------------------------------------------------------------------------------------
 // network table
 // ---------------------------------------------------------------------------------------------
@@ -127,6 +129,27 @@ ConvSrc src_none() { ConvSrc s; s.ptr = nullptr; s.scale = nullptr; s.shift = nu
 
 #define SIFSR_TRY(expr) do { int rc__ = (expr); if (rc__ != SIFSR_OK) return rc__; } while (0)
 
+// ---- optional per-kernel timing (bench.py roofline): HIP events on the launch stream around ONE
+// selected (layer, phase) launch inside the normal schedule.  phase 1 fwd conv, 2 dgrad, 3 wgrad.
+struct ProfState {
+  int layer = -1, phase = 0;
+  std::vector<hipEvent_t> start, stop;
+};
+ProfState g_prof;
+
+struct ProfScope {
+  hipStream_t s; bool on;
+  ProfScope(int layer, int phase, hipStream_t st) : s(st), on(layer == g_prof.layer && phase == g_prof.phase) {
+    if (on) {
+      hipEvent_t e0, e1;
+      if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
+      g_prof.start.push_back(e0); g_prof.stop.push_back(e1);
+      (void)hipEventRecord(e0, s);
+    }
+  }
+  ~ProfScope() { if (on) (void)hipEventRecord(g_prof.stop.back(), s); }
+};
+
 // forward of one MFMA Conv(-BN) unit
 int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, float* running, float momentum, float eps) {
   const LayerInfo& L = c.nt.L[l];
@@ -140,7 +163,10 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
   a.dst_split = L.cout / 16;
   a.B = c.B; a.H = c.lvH(L.level); a.W = c.lvW(L.level);
   a.NQ = L.cin / 16;
-  SIFSR_TRY(launch_conv3x3_mfma(a, L.cout, 0, c.s));
+  {
+    ProfScope ps(l, 1, c.s);
+    SIFSR_TRY(launch_conv3x3_mfma(a, L.cout, 0, c.s));
+  }
   if (training) {
     const int nblk = c.B * (a.H / 16) * (a.W / 16);
     SIFSR_TRY(launch_bn_finalize(c.f(c.lay.partials), nblk, L.cout, (double)c.B * a.H * a.W, c.params + L.gamma_off,
@@ -178,7 +204,10 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
   a.NQ = L.cin / 16;
   a.ntiles = c.B * (a.H / 8) * (a.W / 16);
   const int nblk = wgrad_blocks(L.cin, L.cout, a.ntiles);
-  SIFSR_TRY(launch_conv3x3_wgrad(a, L.cin, L.cout, nblk, c.s));
+  {
+    ProfScope ps(l, 3, c.s);
+    SIFSR_TRY(launch_conv3x3_wgrad(a, L.cin, L.cout, nblk, c.s));
+  }
   SIFSR_TRY(launch_wgrad_reduce(a.slabs, nblk, L.cin, L.cout, grads + L.w_off, c.s));
   return SIFSR_OK;
 }
@@ -198,9 +227,10 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
   a.dst_split = split_ch / 16;
   a.B = c.B; a.H = c.lvH(L.level); a.W = c.lvW(L.level);
   a.NQ = L.cout / 16;
-  SIFSR_TRY(launch_conv3x3_mfma(a, L.cin, 1, c.s));
-  SIFSR_TRY(launch_dgrad_border_fix(dy, L.cout, c.params + L.w_off, L.cin, g0, C0, 0, split_ch, g1 ? g1 : g0,
-                                    g1 ? C1 : C0, 0, c.B, a.H, a.W, c.s));
+  {
+    ProfScope ps(l, 2, c.s);
+    SIFSR_TRY(launch_conv3x3_mfma(a, L.cin, 1, c.s));
+  }
   return SIFSR_OK;
 }
 
@@ -340,5 +370,25 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     if (nblk > 1024) nblk = 1024;
     SIFSR_TRY(launch_conv_in_wgrad(x, c.f(w.g[L_IN0]), c.f(w.slabs), nblk, grads + nt.L[L_IN0].w_off, B, H, W, s));
   }
+  return SIFSR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling hooks
+// ---------------------------------------------------------------------------------------------
+int sifsr_engine_profile_select(int layer, int phase) {
+  for (size_t i = 0; i < g_prof.start.size(); ++i) { (void)hipEventDestroy(g_prof.start[i]); (void)hipEventDestroy(g_prof.stop[i]); }
+  g_prof.start.clear(); g_prof.stop.clear();
+  g_prof.layer = layer; g_prof.phase = phase;
+  return SIFSR_OK;
+}
+int sifsr_engine_profile_read(float* total_ms, int* count) {
+  float tot = 0.f; int n = 0;
+  for (size_t i = 0; i < g_prof.start.size(); ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof.stop[i]) == hipSuccess && hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]) == hipSuccess) { tot += ms; ++n; }
+  }
+  if (total_ms) *total_ms = tot;
+  if (count) *count = n;
   return SIFSR_OK;
 }
