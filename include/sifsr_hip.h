@@ -52,7 +52,8 @@ SIFSR_API int sifsr_model_backward(const float* x, const float* dsr, const float
                                    void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
 
 /* ---- 3x3 convolution pieces (nn.Conv2d(k=3,padding=1,padding_mode='replicate'), model.py:135,138,507) */
-/* OIHW -> MFMA fragment order (forward operand and transposed+flipped dgrad operand), 9*cin*cout floats each */
+/* OIHW -> MFMA fragment order: wfwd 9*cin*cout floats (forward operand); wdgrad 2*9*cin*cout floats
+ * (transposed+flipped dgrad operand followed by a tap-major copy for the replicate-border fold) */
 SIFSR_API int sifsr_pack_conv_weights(const float* w_oihw, int cin, int cout, float* wfwd, float* wdgrad, void* stream);
 /* y = conv(cat([a0, a1], C)), a_i = relu(src_i*scale_i+shift_i) if scale_i != NULL else src_i (NHWC, C_i % 16 == 0;
  * src1 may be NULL).  stat_partials: NULL or [B*(H/16)*(W/16)][cout][2] per-tile (sum, sumsq) of y. */

@@ -83,8 +83,10 @@ int sifsr_conv3x3_dgrad(const float* dy, int cout, const float* wdgrad, const fl
   a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
   a.wpack = wdgrad; a.addend = addend; a.addC = cin; a.stat_partials = nullptr; a.dst_split = C0 / 16;
   a.B = B; a.H = H; a.W = W; a.NQ = cout / 16;
-  (void)w_oihw;   // kept in the signature for ABI stability; the border fold now uses the packed weights
-  return launch_conv3x3_mfma(a, cin, 1, S(stream));
+  (void)w_oihw;   // kept in the signature for ABI stability; the border fold uses the tap-major pack
+  int rc = launch_conv3x3_mfma(a, cin, 1, S(stream));
+  if (rc) return rc;
+  return launch_dgrad_border_fix(dy, cout, wdgrad, cin, g0, C0, C0, g1 ? g1 : g0, g1 ? C1 : C0, B, H, W, S(stream));
 }
 
 size_t sifsr_conv3x3_wgrad_scratch_floats(int cin, int cout, int nblk) { return (size_t)nblk * wgrad_slab_floats(cin, cout); }

@@ -33,8 +33,8 @@ struct ConvArgs {
 };
 
 // conv3x3, stride 1, NHWC fp32, MFMA implicit GEMM.  zero_pad = 0: replicate padding (forward,
-// nn.Conv2d(padding_mode='replicate'), model.py:135); zero_pad = 1: zero padding (dgrad: the
-// transposed conv with the replicate-padding adjoint folded in on image-border tiles).
+// nn.Conv2d(padding_mode='replicate'), model.py:135); zero_pad = 1: zero padding (the interior part
+// of the transposed conv used by dgrad; the replicate-border fold is dgrad_border_fix).
 int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s);
 
 struct WgradArgs {
@@ -49,5 +49,10 @@ struct WgradArgs {
 int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s);
 int launch_wgrad_reduce(const float* slabs, int nblk, int cin, int cout, float* dw_oihw, hipStream_t s);
 size_t wgrad_slab_floats(int cin, int cout);   // floats per block
+
+// dgrad: replicate-padding adjoint fold for the border pixels (adds to g_in).  wdg_layer = the layer's
+// dgrad weight pack [fragment order | tap-major] written by pack_weights.
+int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, int Cin, float* g0, int C0,
+                            int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s);
 
 int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStream_t s);

@@ -1,8 +1,7 @@
 // 3x3 convolution (stride 1) as an implicit GEMM on the fp32 matrix cores of gfx950.
 //
 // Replaces what the reference dispatches to ATen/MKLDNN/cuDNN for nn.Conv2d(k=3, padding=1,
-// padding_mode='replicate', bias=False) -- model.py:135,138,507 -- and its input-gradient (the
-// replicate-padding adjoint is folded in as extra masked taps on image-border tiles).
+// padding_mode='replicate', bias=False) -- model.py:135,138,507 -- and its input-gradient.
 //
 // Mapping (one workgroup = 256 threads = 4 waves, one 16x16-pixel output tile of one image):
 //   * the (16+2)x(16+2) input halo tile of one 16-channel block is staged in LDS as
@@ -109,12 +108,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
     if (q + 1 < NQ) issue_loads(q + 1);   // in flight while this block is multiplied
 
     const int kq = lane >> 4, px = lane & 15;
-    auto mac4 = [&](f32x4& d, const float4& w, const float4& bv) {
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, bv.x, d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, bv.y, d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, bv.z, d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, bv.w, d, 0, 0, 0);
-    };
 #pragma unroll
     for (int gb = 0; gb < NG / 4; ++gb) {
 #pragma unroll
@@ -141,59 +134,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
 #pragma unroll
           for (int gi = 0; gi < 4; ++gi)
             acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, bf[gi].w, acc[c][gb * 4 + gi], 0, 0, 0);
-        }
-      }
-      if (ZERO_PAD && (x0 == 0 || x0 + 16 == W)) {
-        // Replicate-padding adjoint, x direction.  The forward read x[clamp(p+t)]; the gradient of the
-        // clamped reads returns to the border column:  g[q] += W^T_(ty, tx=-1) dy[q - (ty,0)] for qx = 0
-        // and the mirror image for qx = W-1.  In this kernel's correlation form (weights pre-flipped) that
-        // is tap (ty, 2) resp. (ty, 0) applied to the CENTRE column, on the border lanes only.
-        const bool lf = x0 == 0 && px == 0, rt = x0 + 16 == W && px == 15;
-#pragma unroll
-        for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-          for (int gi = 0; gi < 4; ++gi) {
-            const int r = g0 + gb * 4 + gi;
-            const float4 cv = lds[kq * PLANE + (r + ty) * PW + 1 + px];
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int c = 0; c < CBW; ++c) {
-              if (x0 == 0) mac4(acc[c][gb * 4 + gi], wf[c][ty * 3 + 2], lf ? cv : z4);
-              if (x0 + 16 == W) mac4(acc[c][gb * 4 + gi], wf[c][ty * 3 + 0], rt ? cv : z4);
-            }
-          }
-      }
-    }
-    if (ZERO_PAD) {
-      // y direction (and the corners): tile row 0 of an image-top tile / row 15 of an image-bottom tile.
-      const bool lf = x0 == 0 && px == 0, rt = x0 + 16 == W && px == 15;
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (y0 == 0 && g0 == 0) {
-#pragma unroll
-        for (int tx = 0; tx < 3; ++tx) {
-          const float4 bv = lds[kq * PLANE + 1 * PW + tx + px];
-#pragma unroll
-          for (int c = 0; c < CBW; ++c) mac4(acc[c][0], wf[c][6 + tx], bv);
-        }
-        const float4 cv = lds[kq * PLANE + 1 * PW + 1 + px];
-#pragma unroll
-        for (int c = 0; c < CBW; ++c) {
-          if (x0 == 0) mac4(acc[c][0], wf[c][8], lf ? cv : z4);
-          if (x0 + 16 == W) mac4(acc[c][0], wf[c][6], rt ? cv : z4);
-        }
-      }
-      if (y0 + 16 == H && g0 + NG == 16) {
-#pragma unroll
-        for (int tx = 0; tx < 3; ++tx) {
-          const float4 bv = lds[kq * PLANE + 16 * PW + tx + px];
-#pragma unroll
-          for (int c = 0; c < CBW; ++c) mac4(acc[c][NG - 1], wf[c][tx], bv);
-        }
-        const float4 cv = lds[kq * PLANE + 16 * PW + 1 + px];
-#pragma unroll
-        for (int c = 0; c < CBW; ++c) {
-          if (x0 == 0) mac4(acc[c][NG - 1], wf[c][2], lf ? cv : z4);
-          if (x0 + 16 == W) mac4(acc[c][NG - 1], wf[c][0], rt ? cv : z4);
         }
       }
     }
@@ -257,6 +197,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
 //   fwd  : wf[nb][q][tap][lane][j] = W[co = 16nb + (lane&15)][ci = 16q + 4(lane>>4) + j][tap]
 //   dgrad: wd[nb][q][tap][lane][j] = W[co = 16q + 4(lane>>4) + j][ci = 16nb + (lane&15)][8 - tap]
 //          (transposed and spatially flipped: dx[p] = sum_t W_t^T dy[p - t])
+//   border: wb[tap][co][ci] = W[co][ci][tap]   (tap-major, ci contiguous; used by dgrad_border_kernel)
+// The dgrad buffer of a layer holds [wd | wb] = 2 * 9*cin*cout floats.
 // ---------------------------------------------------------------------------------------------
 struct PackTable { int w_off[16], cin[16], cout[16], p_off[16]; };
 
@@ -280,9 +222,75 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
       const int NQ = cout / 16;
       const int q = r2 % NQ, nb = r2 / NQ;
       const int co = 16 * q + 4 * (lane >> 4) + j, ci = 16 * nb + (lane & 15);
-      wdg[tb.p_off[l] + e] = W[(co * cin + ci) * 9 + (8 - tap)];
+      wdg[2 * tb.p_off[l] + e] = W[(co * cin + ci) * 9 + (8 - tap)];
+    }
+    {
+      const int ci = e % cin, co = (e / cin) % cout, t = e / (cin * cout);
+      wdg[2 * tb.p_off[l] + n + e] = W[(co * cin + ci) * 9 + t];
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dgrad border fold.  Forward reads x[clamp(p + t)] (replicate padding); its adjoint sends the
+// gradient of every out-of-range read back to the clamped pixel:
+//   g[q] = sum_t W_t^T * sum_{p : clamp(p+t) = q} dy[p]
+// The MFMA kernel (zero_pad) produced the p = q - t terms; this kernel adds the rest, which exist only
+// for q on the image border.  Per axis the extra source is p = q itself, for (q = 0, t = -1) and
+// (q = N-1, t = +1); the 2-D set is the product of the per-axis sets minus the (base, base) pair.
+// One thread per (border pixel, 4 input channels); weights tap-major so the ci quad is one float4.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void border_accum(float4& acc, const float* __restrict__ d, const float* __restrict__ wt,
+                                             int Cout, int Cin) {
+  for (int co = 0; co < Cout; co += 4) {
+    const float4 dv = ld4(d + co);
+    const float4 w0 = ld4(wt + (size_t)(co + 0) * Cin), w1 = ld4(wt + (size_t)(co + 1) * Cin);
+    const float4 w2 = ld4(wt + (size_t)(co + 2) * Cin), w3 = ld4(wt + (size_t)(co + 3) * Cin);
+    acc.x = fmaf(dv.x, w0.x, acc.x); acc.y = fmaf(dv.x, w0.y, acc.y); acc.z = fmaf(dv.x, w0.z, acc.z); acc.w = fmaf(dv.x, w0.w, acc.w);
+    acc.x = fmaf(dv.y, w1.x, acc.x); acc.y = fmaf(dv.y, w1.y, acc.y); acc.z = fmaf(dv.y, w1.z, acc.z); acc.w = fmaf(dv.y, w1.w, acc.w);
+    acc.x = fmaf(dv.z, w2.x, acc.x); acc.y = fmaf(dv.z, w2.y, acc.y); acc.z = fmaf(dv.z, w2.z, acc.z); acc.w = fmaf(dv.z, w2.w, acc.w);
+    acc.x = fmaf(dv.w, w3.x, acc.x); acc.y = fmaf(dv.w, w3.y, acc.y); acc.z = fmaf(dv.w, w3.z, acc.z); acc.w = fmaf(dv.w, w3.w, acc.w);
+  }
+}
+
+__global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restrict__ dy, int Cout,
+                                                           const float* __restrict__ wb, int Cin, float* g0, int C0,
+                                                           int split_ch, float* g1, int C1, int B, int H, int W) {
+  const int Q = Cin / 4;
+  const int per_img = 2 * W + 2 * (H - 2);
+  const int total = B * per_img * Q;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c4 = e % Q;
+  const int bp = (e / Q) % per_img;
+  const int b = e / (Q * per_img);
+  int qy, qx;
+  if (bp < W) { qy = 0; qx = bp; }
+  else if (bp < 2 * W) { qy = H - 1; qx = bp - W; }
+  else { const int r = bp - 2 * W; qy = 1 + (r >> 1); qx = (r & 1) ? W - 1 : 0; }
+  const float* img = dy + (size_t)b * H * W * Cout;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int ty = -1; ty <= 1; ++ty) {
+    const bool ey = (qy == 0 && ty == -1) || (qy == H - 1 && ty == 1);      // extra source row = qy
+    const bool by = qy - ty >= 0 && qy - ty < H;                            // base source row in range
+#pragma unroll
+    for (int tx = -1; tx <= 1; ++tx) {
+      const bool ex = (qx == 0 && tx == -1) || (qx == W - 1 && tx == 1);
+      const bool bx = qx - tx >= 0 && qx - tx < W;
+      if (!ey && !ex) continue;
+      const float* wt = wb + ((size_t)((ty + 1) * 3 + (tx + 1)) * Cout) * Cin + 4 * c4;
+      if (ey && bx) border_accum(acc, img + ((size_t)qy * W + (qx - tx)) * Cout, wt, Cout, Cin);
+      if (by && ex) border_accum(acc, img + ((size_t)(qy - ty) * W + qx) * Cout, wt, Cout, Cin);
+      if (ey && ex) border_accum(acc, img + ((size_t)qy * W + qx) * Cout, wt, Cout, Cin);
+    }
+  }
+  const size_t pix = (size_t)(b * H + qy) * W + qx;
+  const int ci = 4 * c4;
+  float* dst = ci < split_ch ? g0 + pix * C0 + ci : g1 + pix * C1 + (ci - split_ch);
+  float4 v = ld4(dst);
+  v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
+  st4(dst, v);
 }
 
 }  // namespace
@@ -333,6 +341,16 @@ int launch_pack_weights_one(const float* w, int cin, int cout, float* wfwd, floa
   const int n = 9 * cin * cout;
   const dim3 grid((n + 255) / 256 > 64 ? 64 : (n + 255) / 256, 1);
   hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, s, w, wfwd, wdg, tb);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, int Cin, float* g0, int C0,
+                            int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s) {
+  const int total = B * (2 * W + 2 * (H - 2)) * (Cin / 4);
+  const float* wb = wdg_layer + (size_t)9 * Cin * Cout;   // tap-major copy behind the fragment-ordered one
+  hipLaunchKernelGGL(dgrad_border_kernel, dim3((total + 255) / 256), dim3(256), 0, s, dy, Cout, wb, Cin, g0, C0,
+                     split_ch, g1, C1, B, H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

@@ -66,7 +66,7 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
 
   w.mean = take(nt.total_channels); w.invstd = take(nt.total_channels);
   w.scale = take(nt.total_channels); w.shift = take(nt.total_channels);
-  w.wfwd = take(nt.total_wpack); w.wdg = take(nt.total_wpack);
+  w.wfwd = take(nt.total_wpack); w.wdg = take(2 * (size_t)nt.total_wpack);
   for (int l = 0; l < SIFSR_NUM_BN_LAYERS; ++l) w.y[l] = take(nt.L[l].cout * N[nt.L[l].level]);
   static const int pc[3] = {16, 32, 64};
   for (int k = 0; k < 3; ++k) {
@@ -221,7 +221,7 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
   a.src[0] = src_raw(dy, L.cout); a.src[1] = src_none();
   a.dst[0].ptr = g0; a.dst[0].C = C0; a.dst[0].coff = 0;
   a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
-  a.wpack = c.f(c.lay.wdg) + L.wpack_off;
+  a.wpack = c.f(c.lay.wdg) + 2 * (size_t)L.wpack_off;
   a.addend = addend; a.addC = L.cin;
   a.stat_partials = nullptr;
   a.dst_split = split_ch / 16;
@@ -231,6 +231,8 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
     ProfScope ps(l, 2, c.s);
     SIFSR_TRY(launch_conv3x3_mfma(a, L.cin, 1, c.s));
   }
+  SIFSR_TRY(launch_dgrad_border_fix(dy, L.cout, a.wpack, L.cin, g0, C0, split_ch, g1 ? g1 : g0, g1 ? C1 : C0, c.B, a.H,
+                                    a.W, c.s));
   return SIFSR_OK;
 }
 

@@ -93,7 +93,7 @@ def test_conv3x3_fwd_dgrad_wgrad(L, case):
     d1 = dev(nhwc(x1)) if C1 else None
     dsc0, dsh0 = (dev(sc0), dev(sh0)) if aff0 else (None, None)
     dsc1, dsh1 = (dev(sc1), dev(sh1)) if sc1 is not None else (None, None)
-    wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty_like(wf)
+    wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(2 * 9 * cin * cout, device="cuda")
     L.call("sifsr_pack_conv_weights", dw_, cin, cout, wf, wd, S())
 
     # ---- forward + BN statistic partials ----
