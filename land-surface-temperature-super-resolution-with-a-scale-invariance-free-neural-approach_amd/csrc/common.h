@@ -38,7 +38,7 @@ static __device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh
 }
 
 // ---------------------------------------------------------------------------------------------
-// Network table (mirrors oracle/sif_oracle.py CONV_BN_LAYERS == reference state_dict order)
+// Network table (== reference state_dict order, model.py:596-605; checked by tests/test_capi_symbols.py)
 // ---------------------------------------------------------------------------------------------
 #define SIFSR_NUM_BN_LAYERS 17
 #define SIFSR_NUM_PARAMS 282705

@@ -185,13 +185,14 @@ int launch_wgrad_t(const WgradArgs& a, int chunks, int nblk, hipStream_t s) {
 
 size_t wgrad_slab_floats(int cin, int cout) { return (size_t)9 * cin * cout; }
 
-static int wgrad_nbi_chunk(int cin) { return cin > 64 ? 4 : cin / 16; }
+// Cin is processed in chunks of <= 32 channels (blockIdx.y): keeps LDS <= 76 KB so two workgroups fit a CU
+static int wgrad_nbi_chunk(int cin) { return cin >= 32 ? 2 : 1; }
 
 int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s) {
   if (a.H % WT_ROWS || a.W % 16 || cin % 16 || cout % 16 || nblk < 1) return SIFSR_ERR_SHAPE;
   const int nbi = wgrad_nbi_chunk(cin), chunks = (cin / 16) / nbi, nbo = cout / 16;
 #define SIFSR_WG(NBOV, NBIV) if (nbo == NBOV && nbi == NBIV) return launch_wgrad_t<NBOV, NBIV>(a, chunks, nblk, s);
-  SIFSR_WG(1, 1) SIFSR_WG(1, 2) SIFSR_WG(2, 1) SIFSR_WG(2, 2) SIFSR_WG(4, 2) SIFSR_WG(2, 4) SIFSR_WG(4, 4)
+  SIFSR_WG(1, 1) SIFSR_WG(1, 2) SIFSR_WG(2, 1) SIFSR_WG(2, 2) SIFSR_WG(4, 2)
 #undef SIFSR_WG
   return SIFSR_ERR_SHAPE;
 }

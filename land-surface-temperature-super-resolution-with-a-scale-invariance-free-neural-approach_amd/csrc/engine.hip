@@ -50,8 +50,13 @@ const NetTable& sifsr_net() {
 static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }   // in floats (256 B)
 
 static int wgrad_blocks(int cin, int cout, int ntiles) {
-  const int cap = (size_t)9 * cin * cout <= 9216 ? 512 : 256;
-  return ntiles < cap ? ntiles : cap;
+  // persistent workgroups; blockIdx.y additionally splits Cin into 32-channel chunks.  Enough of them to
+  // fill every CU several times over (the slab each one writes is 9*cin*cout floats / chunk count).
+  const size_t slab = (size_t)9 * cin * cout;
+  const int cap = slab <= 4608 ? 2048 : (slab <= 18432 ? 1024 : 512);
+  const int chunks = cin >= 64 ? cin / 32 : 1;
+  int n = cap / chunks;
+  return ntiles < n ? ntiles : n;
 }
 
 int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {

@@ -1,0 +1,118 @@
+"""CPU: host-side mirror of the reference interface (no GPU needed): module layout, error behaviour,
+PSF taps, synthetic dataset contract, shard arithmetic."""
+import copy
+import io
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sif_oracle as O
+
+
+@pytest.fixture(scope="module")
+def sifsr():
+    import sifsr as pkg
+    return pkg
+
+
+def test_model_container_matches_reference_state_dict(sifsr, golden):
+    m = sifsr.ModelB_2(in_channels=2, downchannels=[16, 32, 64, 128], padding_mode="replicate", activation="ReLU",
+                       bilinear=1, n_bridge_blocks=1)
+    spec = [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+    assert spec == golden["state_dict_spec"]
+    assert [n for n, _ in m.named_parameters()] == O.param_names()
+    assert (m.in_channels, m.downchannels, m.padding, m.activation, m.upfactor, m.bridge) == \
+           (2, [16, 32, 64, 128], "replicate", "ReLU", 2, 1)
+    m.load_state_dict(O.synthetic_state(1), strict=True)
+    assert isinstance(m.db1.downsampling, torch.nn.AvgPool2d) and isinstance(m.ub1.up, torch.nn.Upsample)
+
+
+def test_unsupported_options_raise(sifsr):
+    for bad in (dict(padding_mode="zeros"), dict(activation="Serf"), dict(bilinear=False), dict(downchannels=[8, 16, 32, 64])):
+        with pytest.raises(NotImplementedError):
+            sifsr.ModelB_2(2, **bad)
+    with pytest.raises(NotImplementedError):
+        sifsr.ModelB_2(3)
+
+
+def test_no_cpu_fallback(sifsr):
+    m = sifsr.ModelB_2(2)
+    with pytest.raises(sifsr.SifsrError):
+        m(torch.zeros(1, 2, 256, 256))
+    x = torch.zeros(1, 1, 256, 256)
+    for fn in (sifsr.downscale_LST_SR_to_LR, sifsr.get_output_ftm, sifsr.sobel_bank):
+        with pytest.raises(sifsr.SifsrError):
+            fn(x)
+    with pytest.raises(sifsr.SifsrError):
+        sifsr.sif_loss("sr2", x, torch.zeros(1, 1, 64, 64), x, 0.0, 1.0, 0.5, -0.25)
+    with pytest.raises(NotImplementedError):
+        sifsr.downscale_LST_SR_to_LR(x, deci_type="norm-L4")
+    with pytest.raises(NotImplementedError):
+        sifsr.get_output_ftm(x, factor=2)
+
+
+def test_product_never_imports_oracle(sifsr):
+    import os
+    root = os.path.dirname(sifsr.__file__)
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "sif_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_pickle_and_deepcopy_on_cpu(sifsr):
+    m = sifsr.ModelB_2(2)
+    m.load_state_dict(O.synthetic_state(2))
+    m2 = pickle.loads(pickle.dumps(m))
+    m3 = copy.deepcopy(m)
+    for a, b, c in zip(m.state_dict().values(), m2.state_dict().values(), m3.state_dict().values()):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    buf = io.BytesIO(); torch.save(m.state_dict(), buf); buf.seek(0)
+    sd = torch.load(buf, weights_only=True)
+    assert list(sd.keys()) == [n for n, _, _ in O.state_dict_spec()]
+
+
+def test_psf_taps(sifsr, golden):
+    for mtf in (0.1, 0.25):
+        t = sifsr.sif_ops.psf_taps_1d(mtf)
+        np.testing.assert_allclose(t, golden["cases"][f"psf_{mtf}"]["taps1d"], rtol=0, atol=1e-15)
+        k = np.array(golden["cases"][f"psf_{mtf}"]["kernel9x9"], dtype=np.float64).reshape(9, 9)   # the reference's kernel
+        assert np.abs(np.outer(t, t) - k).max() < 2e-8
+    with pytest.raises(NotImplementedError):
+        sifsr.sif_ops._taps_c(0.1, 4, 3)
+
+
+def test_synthetic_dataset_contract(sifsr):
+    ds = sifsr.ModisDatasetB(None, transf="norm", split="Train", time="Both", length=5)
+    assert len(ds) == 5 and set(ds.stats) == {"mean_lst", "std_lst", "mean_ndvi", "std_ndvi"}
+    lst, lst_up, ndvi = ds[3]
+    assert lst.shape == (1, 64, 64) and lst_up.shape == (1, 256, 256) and ndvi.shape == (1, 256, 256)
+    assert lst.dtype == lst_up.dtype == ndvi.dtype == np.float32
+    assert np.array_equal(ds[3][0], lst) and not np.array_equal(ds[2][0], lst)
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2)))
+    assert [tuple(t.shape) for t in batch] == [(2, 1, 64, 64), (2, 1, 256, 256), (2, 1, 256, 256)]
+    with pytest.raises(IndexError):
+        ds[5]
+
+
+def test_shard_range_covers_everything(sifsr):
+    from sifsr.distributed import shard_range
+    for n in (0, 1, 7, 64, 324):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_tile_granule(sifsr):
+    lst = torch.arange(130 * 200, dtype=torch.float32).view(130, 200)
+    ndvi = torch.zeros(520, 800)
+    t, n, pos = sifsr.predict.tile_granule(lst, ndvi)
+    assert t.shape == (6, 1, 64, 64) and n.shape == (6, 1, 256, 256)        # ragged edges skipped (predict.py:95)
+    assert pos == [(0, 0), (0, 64), (0, 128), (64, 0), (64, 64), (64, 128)]
+    assert torch.equal(t[4, 0], lst[64:128, 64:128])
