@@ -56,7 +56,8 @@ SIFSR_API int sifsr_model_backward(const float* x, const float* dsr, const float
  * (transposed+flipped dgrad operand followed by a tap-major copy for the replicate-border fold) */
 SIFSR_API int sifsr_pack_conv_weights(const float* w_oihw, int cin, int cout, float* wfwd, float* wdgrad, void* stream);
 /* y = conv(cat([a0, a1], C)), a_i = relu(src_i*scale_i+shift_i) if scale_i != NULL else src_i (NHWC, C_i % 16 == 0;
- * src1 may be NULL).  stat_partials: NULL or [B*(H/16)*(W/16)][cout][2] per-tile (sum, sumsq) of y. */
+ * src1 may be NULL).  stat_partials: NULL or [sifsr_conv3x3_stat_blocks()][cout][2] per-workgroup (sum, sumsq) of y. */
+SIFSR_API int sifsr_conv3x3_stat_blocks(int B, int H, int W, int cout);
 SIFSR_API int sifsr_conv3x3_fwd(const float* src0, int C0, const float* scale0, const float* shift0,
                                 const float* src1, int C1, const float* scale1, const float* shift1,
                                 const float* wfwd, float* y, int cout, float* stat_partials, int B, int H, int W,

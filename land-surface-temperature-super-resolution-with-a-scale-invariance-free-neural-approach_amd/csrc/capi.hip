@@ -60,6 +60,8 @@ int sifsr_pack_conv_weights(const float* w_oihw, int cin, int cout, float* wfwd,
   return launch_pack_weights_one(w_oihw, cin, cout, wfwd, wdgrad, S(stream));
 }
 
+int sifsr_conv3x3_stat_blocks(int B, int H, int W, int cout) { return conv3x3_grid_blocks(B, H, W, cout); }
+
 int sifsr_conv3x3_fwd(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
                       const float* scale1, const float* shift1, const float* wfwd, float* y, int cout,
                       float* stat_partials, int B, int H, int W, void* stream) {

@@ -25,7 +25,7 @@ struct ConvArgs {
   ConvDst dst[2];       // output channel blocks [0, dst_split) -> dst[0], the rest -> dst[1]
   const float* wpack;   // fragment-ordered weights, see pack_weights_kernel
   const float* addend;  // optional tensor added to dst[0] in the epilogue (residual gradient), C = addC
-  float* stat_partials; // optional [grid blocks][Cout][2] per-block (sum, sum of squares) of the output
+  float* stat_partials; // optional [conv3x3_grid_blocks()][Cout][2] per-workgroup (sum, sum of squares) of the output
   int addC;
   int dst_split;        // in 16-channel blocks
   int B, H, W;
@@ -36,6 +36,7 @@ struct ConvArgs {
 // nn.Conv2d(padding_mode='replicate'), model.py:135); zero_pad = 1: zero padding (the interior part
 // of the transposed conv used by dgrad; the replicate-border fold is dgrad_border_fix).
 int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s);
+int conv3x3_grid_blocks(int B, int H, int W, int cout);   // workgroups launched == stat_partials rows written
 
 struct WgradArgs {
   ConvSrc src[2];      // the conv's forward input (same description as in the forward call)

@@ -3,7 +3,8 @@
 // Replaces what the reference dispatches to ATen/MKLDNN/cuDNN for nn.Conv2d(k=3, padding=1,
 // padding_mode='replicate', bias=False) -- model.py:135,138,507 -- and its input-gradient.
 //
-// Mapping (one workgroup = 256 threads = 4 waves, one 16x16-pixel output tile of one image):
+// Mapping (one workgroup = 256 threads = 4 waves; PERSISTENT: it walks 16x16-pixel output tiles and
+// prefetches the next tile's halo into registers while the matrix cores work on the current one):
 //   * the (16+2)x(16+2) input halo tile of one 16-channel block is staged in LDS as
 //     [channel-quad k][pixel][4 channels]  (plane stride 336 pixels = 0 mod 16 slots), with the
 //     producing layer's BatchNorm+ReLU folded into the staging (relu(x*scale+shift));
@@ -19,27 +20,162 @@
 //     reduced with wave shuffles + LDS and written per workgroup (deterministic 2-stage reduction).
 #include "conv.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int PW = 18;        // plane width  (16 + 2 halo)
 constexpr int PLANE = 336;    // 18*18 = 324 pixels, padded to a multiple of 16 (bank rule)
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// Raw buffer access (T8 of the CDNA guide): 128-bit descriptor in SGPRs + 32-bit per-lane byte offset +
+// scalar byte offset.  Per-lane offsets at or beyond num_records read as 0 (used for dgrad's zero padding);
+// the scalar offset is not part of that check.
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+static __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+static __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 v) {
+  u32x4 u;
+  u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, (int)soff, 0);
+}
+constexpr unsigned OOB = 0xFFFFFF00u;   // per-lane offset beyond any tensor: buffer loads return 0
+
 template <int NB, bool ZERO_PAD>
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a, const int ntiles, const int lgx,
+                                                           const int lgy) {
   constexpr int CBW = NB >= 4 ? NB / 4 : 1;                 // cout blocks per wave
   constexpr int NG = NB == 1 ? 4 : (NB == 2 ? 8 : 16);      // tile rows per wave
 
-  __shared__ float4 lds[4 * PLANE];
+  __shared__ float4 lds[2][4 * PLANE];                       // double buffered: one barrier per 16-channel block
   __shared__ float red[4][CBW][16][2];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16, b = blockIdx.z;
   const int H = a.H, W = a.W;
+  const int tiles_x = W / 16, tiles_y = H / 16;
+  const int NQ = a.NQ;
+  const unsigned npix = (unsigned)a.B * (unsigned)H * (unsigned)W;
 
   const int nb0 = NB == 1 ? 0 : (NB == 2 ? (wave & 1) : wave);
   const int g0 = NB == 1 ? wave * 4 : (NB == 2 ? (wave >> 1) * 8 : 0);
+  const int kq = lane >> 4, px = lane & 15;
+
+  // ---- descriptors (wave-uniform) ----
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.src[0].ptr, npix * a.src[0].C * 4u);
+  const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.src[1].ptr ? a.src[1].ptr : a.src[0].ptr, npix * (a.src[1].ptr ? a.src[1].C : a.src[0].C) * 4u);
+  const __amdgpu_buffer_rsrc_t rd0 = make_rsrc(a.dst[0].ptr, npix * a.dst[0].C * 4u);
+  const __amdgpu_buffer_rsrc_t rd1 = make_rsrc(a.dst[1].ptr, npix * a.dst[1].C * 4u);
+  const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.addend ? a.addend : a.dst[0].ptr, npix * (a.addend ? a.addC : a.dst[0].C) * 4u);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpack, (unsigned)(NB * 16) * (unsigned)(NQ * 16) * 36u);
+
+  // ---- persistent tile walk.  Workgroups b, b+8, ... are observed to share an XCD (private L2), so each
+  // residue class gets one contiguous range of tiles, walked with stride G/8 so that concurrently running
+  // workgroups touch neighbouring tiles (speed only; any placement is correct).  Contiguous per-workgroup
+  // chunks were measured slower (large power-of-two strides between concurrent workgroups).
+  const int G = gridDim.x;
+  const bool xcd_map = (G % 8 == 0) && (ntiles % 8 == 0);
+  const int t_lo = xcd_map ? (blockIdx.x % 8) * (ntiles / 8) : 0;
+  const int t_hi = xcd_map ? t_lo + ntiles / 8 : ntiles;
+  const int t_step = xcd_map ? G / 8 : G;
+  int t = t_lo + (xcd_map ? blockIdx.x / 8 : blockIdx.x);
+
+  // ---- staging map: thread -> (channel quad cg, 6 halo pixels).  Interior tiles: the 6 pixel offsets
+  // relative to the halo origin are tile-independent constants; the tile position is a SCALAR offset.
+  const int cg = tid & 3;
+  const int pslot = tid >> 2;
+  int spy[6], spx[6], prel[6];
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    int p = pslot + 64 * it;
+    if (p >= PW * PW) p = PW * PW - 1;           // lanes past the plane re-load the last pixel and do not store it
+    spy[it] = p / PW;
+    spx[it] = p - spy[it] * PW;
+    prel[it] = spy[it] * W + spx[it];
+  }
+  int pixv[6];                  // per-lane pixel index of the tile being prefetched (-1: outside, dgrad only)
+  int pix_base = 0;             // scalar pixel offset added to pixv (interior tiles)
+  auto set_tile = [&](int tt, int& tb, int& ty0, int& tx0) {
+    int txi, tyi;
+    if (lgx >= 0) { tyi = (tt >> lgx) & (tiles_y - 1); tb = tt >> (lgx + lgy); txi = (tt + tyi + tb) & (tiles_x - 1); }   // column rotated per row: no workgroup is pinned to a border column
+    else { txi = tt % tiles_x; const int r = tt / tiles_x; tyi = r % tiles_y; tb = r / tiles_y; }
+    tx0 = txi * 16; ty0 = tyi * 16;
+    const bool interior = txi > 0 && tyi > 0 && txi + 1 < tiles_x && tyi + 1 < tiles_y;
+    if (interior) {
+      pix_base = (tb * H + ty0 - 1) * W + tx0 - 1;
+#pragma unroll
+      for (int it = 0; it < 6; ++it) pixv[it] = prel[it];
+    } else {
+      pix_base = 0;
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const int gy = ty0 - 1 + spy[it], gx = tx0 - 1 + spx[it];
+        const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int pc = (tb * H + clampi(gy, 0, H - 1)) * W + clampi(gx, 0, W - 1);
+        pixv[it] = (ZERO_PAD && !inside) ? -1 : pc;
+      }
+    }
+  };
+
+  // Prefetch registers: loads are issued right after the barrier and not touched until the LDS write of
+  // the next pipeline step, so their latency hides behind the MFMA loop; the producer's BatchNorm+ReLU is
+  // applied at that write.
+  float4 stg[6], psc, psh;
+  bool praw = true;
+  auto issue_loads = [&](int q) {
+    const bool first = q < a.src[0].nq;
+    const int C = first ? a.src[0].C : a.src[1].C;
+    const int lgc = 31 - __builtin_clz((unsigned)C) + 2;                       // log2(C * 4 bytes)
+    const int ch = (first ? a.src[0].coff + 16 * q : a.src[1].coff + 16 * (q - a.src[0].nq));
+    const unsigned soff = ((unsigned)pix_base << lgc) + (unsigned)ch * 4u;
+    const __amdgpu_buffer_rsrc_t r = first ? rs0 : rs1;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const unsigned voff = (ZERO_PAD && pixv[it] < 0) ? OOB : (((unsigned)pixv[it] << lgc) + (unsigned)cg * 16u);
+      stg[it] = bload4(r, voff, soff);
+    }
+    const float* scp = first ? a.src[0].scale : a.src[1].scale;
+    const float* shp = first ? a.src[0].shift : a.src[1].shift;
+    praw = scp == nullptr;
+    if (!praw) { psc = ld4(scp + ch + 4 * cg); psh = ld4(shp + ch + 4 * cg); }
+  };
+  auto write_stage = [&](float4* Lb) {
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      float4 v = stg[it];
+      if (!praw) v = bn_relu4(v, psc, psh);
+      if (it < 5 || pslot < PW * PW - 320) Lb[cg * PLANE + pslot + 64 * it] = v;
+    }
+  };
+
+  float4 wf[CBW][9];
+  auto load_weights = [&](int q) {
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) {
+      const int nb = nb0 + 4 * c;
+      const unsigned soff = (unsigned)((nb * NQ + q) * 9) * 1024u;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) wf[c][tp] = bload4(rw, (unsigned)lane * 16u, soff + tp * 1024u);
+    }
+  };
+
+  float s1[CBW][4], s2[CBW][4];
+#pragma unroll
+  for (int c = 0; c < CBW; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[c][r] = s2[c][r] = 0.f;
+
+  int cb, cy0, cx0;            // tile being computed
+  set_tile(t, cb, cy0, cx0);
+  issue_loads(0);
+  if (NQ == 1) load_weights(0);   // single 16-channel block: weights stay in registers for every tile
+  int buf = 0, q = 0;
 
   f32x4 acc[CBW][NG];
 #pragma unroll
@@ -47,81 +183,35 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[c][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- staging map: thread -> (channel quad cg, 6 halo pixels) ----
-  const int cg = tid & 3;
-  const int pslot = tid >> 2;
-  int poff[6];
-#pragma unroll
-  for (int it = 0; it < 6; ++it) {
-    const int p = pslot + 64 * it;
-    const int py = p / PW, px = p - py * PW;
-    int gy = y0 - 1 + py, gx = x0 - 1 + px;
-    bool ok = p < PW * PW;
-    if (ZERO_PAD) {
-      ok = ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    } else {
-      gy = clampi(gy, 0, H - 1);
-      gx = clampi(gx, 0, W - 1);
-    }
-    poff[it] = ok ? (b * H + gy) * W + gx : -1;
-  }
+  // Flat pipeline over (tile, 16-channel block) work items.  There is exactly ONE issue_loads site, so the
+  // prefetch registers are never a phi of two in-flight loads (which hipcc resolves with vmcnt(0) + moves).
+  while (true) {
+    if (NQ > 1) load_weights(q);
+    write_stage(lds[buf]);
+    __syncthreads();   // buf is complete; the other buffer's readers finished before the previous barrier
 
-  float4 stg[6];
-  auto issue_loads = [&](int q) {
-    const bool first = q < a.src[0].nq;
-    const ConvSrc& s = first ? a.src[0] : a.src[1];
-    const int ch = s.coff + 16 * (first ? q : q - a.src[0].nq) + 4 * cg;
-#pragma unroll
-    for (int it = 0; it < 6; ++it) {
-      stg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (poff[it] >= 0) stg[it] = ld4(s.ptr + (size_t)poff[it] * s.C + ch);
-    }
-    if (s.scale != nullptr) {
-      const float4 sc = ld4(s.scale + ch), sh = ld4(s.shift + ch);
-#pragma unroll
-      for (int it = 0; it < 6; ++it)
-        if (poff[it] >= 0) stg[it] = bn_relu4(stg[it], sc, sh);
-    }
-  };
+    const bool last_q = q + 1 == NQ;
+    const int t_next = t + t_step;
+    const bool more = !last_q || t_next < t_hi;
+    int nb_ = cb, ny0 = cy0, nx0 = cx0;
+    if (last_q && more) set_tile(t_next, nb_, ny0, nx0);
+    if (more) issue_loads(last_q ? 0 : q + 1);
 
-  const int NQ = a.NQ;
-  issue_loads(0);
-
-  for (int q = 0; q < NQ; ++q) {
-    // weights of this 16-channel block for my cout block(s): 9 taps x float4 (4 k-steps)
-    float4 wf[CBW][9];
-#pragma unroll
-    for (int c = 0; c < CBW; ++c) {
-      const int nb = nb0 + 4 * c;
-      const float* wp = a.wpack + ((size_t)(nb * NQ + q) * 9) * 256 + lane * 4;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) wf[c][t] = ld4(wp + t * 256);
-    }
-
-    __syncthreads();   // every wave is done reading the previous block's tile
-#pragma unroll
-    for (int it = 0; it < 6; ++it) {
-      const int p = pslot + 64 * it;
-      if (p < PW * PW) lds[cg * PLANE + p] = stg[it];
-    }
-    __syncthreads();
-    if (q + 1 < NQ) issue_loads(q + 1);   // in flight while this block is multiplied
-
-    const int kq = lane >> 4, px = lane & 15;
+    const float4* L = lds[buf];
 #pragma unroll
     for (int gb = 0; gb < NG / 4; ++gb) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int ty = t / 3, tx = t - 3 * (t / 3);
+      for (int tp = 0; tp < 9; ++tp) {
+        const int ty = tp / 3, tx = tp - 3 * (tp / 3);
         float4 bf[4];
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
           const int r = g0 + gb * 4 + gi;
-          bf[gi] = lds[kq * PLANE + (r + ty) * PW + tx + px];
+          bf[gi] = L[kq * PLANE + (r + ty) * PW + tx + px];
         }
 #pragma unroll
         for (int c = 0; c < CBW; ++c) {
-          const float4 w = wf[c][t];
+          const float4 w = wf[c][tp];
 #pragma unroll
           for (int gi = 0; gi < 4; ++gi)
             acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, bf[gi].x, acc[c][gb * 4 + gi], 0, 0, 0);
@@ -137,33 +227,40 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
         }
       }
     }
-  }
+    buf ^= 1;
+    if (!last_q) { ++q; continue; }
 
-  // ---- epilogue: NHWC stores (+ residual addend) and per-channel statistics ----
-  const int kq = lane >> 4, px = lane & 15;
-  float s1[CBW][4], s2[CBW][4];
+    // ---- tile epilogue: NHWC stores (+ residual addend), running per-channel statistics.
+    // scalar offset = tile row start; per-lane offset = (pixel column, 4-channel group) constant.
+    const unsigned tile_pix = (unsigned)((cb * H + cy0 + g0) * W + cx0);
 #pragma unroll
-  for (int c = 0; c < CBW; ++c) {
-    const int nb = nb0 + 4 * c;
-    const bool d0 = nb < a.dst_split;
-    const ConvDst& d = d0 ? a.dst[0] : a.dst[1];
-    const int ch = d.coff + 16 * (d0 ? nb : nb - a.dst_split) + 4 * kq;
+    for (int c = 0; c < CBW; ++c) {
+      const int nb = nb0 + 4 * c;
+      const bool d0 = nb < a.dst_split;
+      const int dC = d0 ? a.dst[0].C : a.dst[1].C;
+      const __amdgpu_buffer_rsrc_t rd = d0 ? rd0 : rd1;
+      const unsigned chb = (unsigned)((d0 ? a.dst[0].coff + 16 * nb : a.dst[1].coff + 16 * (nb - a.dst_split)) + 4 * kq) * 4u;
+      const unsigned vo = (unsigned)px * (unsigned)dC * 4u + chb;
+      const unsigned va = (unsigned)px * (unsigned)a.addC * 4u + (unsigned)(16 * nb + 4 * kq) * 4u;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s1[c][r] = s2[c][r] = 0.f;
+      for (int g = 0; g < NG; ++g) {
+        const unsigned rowpix = tile_pix + (unsigned)(g * W);
+        f32x4 v = acc[c][g];
+        if (a.addend != nullptr) {
+          const float4 ad = bload4(rad, va, rowpix * (unsigned)a.addC * 4u);
+          v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+        }
+        bstore4(rd, vo, rowpix * (unsigned)dC * 4u, make_float4(v[0], v[1], v[2], v[3]));
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const size_t pix = (size_t)(b * H + y0 + g0 + g) * W + x0 + px;
-      f32x4 v = acc[c][g];
-      if (a.addend != nullptr) {
-        const float4 ad = ld4(a.addend + pix * a.addC + 16 * nb + 4 * kq);
-        v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+        for (int r = 0; r < 4; ++r) { s1[c][r] += v[r]; s2[c][r] = fmaf(v[r], v[r], s2[c][r]); }
+        acc[c][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-      st4(d.ptr + pix * d.C + ch, make_float4(v[0], v[1], v[2], v[3]));
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[c][r] += v[r]; s2[c][r] = fmaf(v[r], v[r], s2[c][r]); }
     }
+    if (!more) break;
+    t = t_next; cb = nb_; cy0 = ny0; cx0 = nx0; q = 0;
   }
 
+  // ---- per-workgroup BatchNorm partials (sum, sumsq) over all tiles this workgroup produced ----
   if (a.stat_partials != nullptr) {
 #pragma unroll
     for (int c = 0; c < CBW; ++c)
@@ -185,8 +282,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
       } else {
         u = red[nb & 3][nb >> 2][cc][0]; v = red[nb & 3][nb >> 2][cc][1];
       }
-      const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      float* o = a.stat_partials + (blk * (NB * 16) + tid) * 2;
+      float* o = a.stat_partials + ((size_t)blockIdx.x * (NB * 16) + tid) * 2;
       o[0] = u; o[1] = v;
     }
   }
@@ -295,15 +391,41 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
 
 }  // namespace
 
+// Number of persistent workgroups (== rows of stat_partials written) for a B x H x W conv with cout outputs:
+// at most 256 CUs x the residency the kernel variant reaches, and an even split of the tiles.
+int conv3x3_grid_blocks(int B, int H, int W, int cout) {
+  const int ntiles = B * (H / 16) * (W / 16);
+  const int per_cu = cout >= 64 ? 1 : 2;   // residency of the kernel variants (VGPR-limited)
+  static const int dbg_grid = getenv("SIFSR_DBG_CONV_GRID") ? atoi(getenv("SIFSR_DBG_CONV_GRID")) : 0;   // tuning knob
+  const int gmax = dbg_grid > 0 ? dbg_grid : 256 * per_cu;
+  if (ntiles <= gmax) return ntiles;
+  const int rounds = (ntiles + gmax - 1) / gmax;
+  int g = (ntiles + rounds - 1) / rounds;
+  g = (g + 7) & ~7;                      // keep the XCD-contiguous mapping available
+  return g < ntiles ? g : ntiles;
+}
+
 int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s) {
   if (a.H % 16 || a.W % 16 || cout % 16 || a.NQ < 1 || a.src[0].nq + a.src[1].nq != a.NQ) return SIFSR_ERR_SHAPE;
   if (!a.src[0].ptr || !a.dst[0].ptr || !a.wpack) return SIFSR_ERR_ARG;
-  const dim3 grid(a.W / 16, a.H / 16, a.B), block(256);
+  const int ntiles = a.B * (a.H / 16) * (a.W / 16);
+  const dim3 grid(conv3x3_grid_blocks(a.B, a.H, a.W, cout)), block(256);
   const int nb = cout / 16;
-#define SIFSR_CONV_CASE(NBV)                                                                      \
-  case NBV:                                                                                       \
-    if (zero_pad) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, true>), grid, block, 0, s, a);     \
-    else hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, false>), grid, block, 0, s, a);             \
+  // 32-bit byte offsets (buffer addressing): every tensor must stay below 4 GiB; channel counts powers of two
+  const size_t npix = (size_t)a.B * a.H * a.W;
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+  int cmax = a.src[0].C > a.src[1].C ? a.src[0].C : a.src[1].C;
+  cmax = cmax > a.dst[0].C ? cmax : a.dst[0].C;
+  cmax = cmax > a.dst[1].C ? cmax : a.dst[1].C;
+  if (npix * cmax * 4 >= ((size_t)1 << 32) - 4096) return SIFSR_ERR_SHAPE;
+  if (!pow2(a.src[0].C) || (a.src[1].ptr && !pow2(a.src[1].C))) return SIFSR_ERR_SHAPE;
+  const int tx_ = a.W / 16, ty_ = a.H / 16;
+  const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
+#define SIFSR_CONV_CASE(NBV)                                                                              \
+  case NBV:                                                                                               \
+    if (zero_pad) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, true>), grid, block, 0, s, a, ntiles, lgx, lgy);     \
+    else hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, false>), grid, block, 0, s, a, ntiles, lgx, lgy);             \
     break;
   switch (nb) {
     SIFSR_CONV_CASE(1)

@@ -173,7 +173,7 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
     SIFSR_TRY(launch_conv3x3_mfma(a, L.cout, 0, c.s));
   }
   if (training) {
-    const int nblk = c.B * (a.H / 16) * (a.W / 16);
+    const int nblk = conv3x3_grid_blocks(c.B, a.H, a.W, L.cout);
     SIFSR_TRY(launch_bn_finalize(c.f(c.lay.partials), nblk, L.cout, (double)c.B * a.H * a.W, c.params + L.gamma_off,
                                  c.params + L.beta_off, running + L.run_off, running + L.run_off + L.cout, momentum, eps,
                                  c.f(c.lay.mean) + L.ch_off, c.f(c.lay.invstd) + L.ch_off,

@@ -98,7 +98,7 @@ def test_conv3x3_fwd_dgrad_wgrad(L, case):
 
     # ---- forward + BN statistic partials ----
     y = torch.empty(B, H, W, cout, device="cuda")
-    nblk = B * (H // 16) * (W // 16)
+    nblk = L.call("sifsr_conv3x3_stat_blocks", B, H, W, cout)
     part = torch.empty(nblk, cout, 2, device="cuda")
     L.call("sifsr_conv3x3_fwd", d0, C0, dsc0, dsh0, d1, C1, dsc1, dsh1, wf, y, cout, part, B, H, W, S())
     torch.cuda.synchronize()

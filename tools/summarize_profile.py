@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_round.sh output directory into profiles/<tag>_summary.md + copies of the CSV stats.
+
+usage: python tools/summarize_profile.py gpurun_out/r01 r01 [steps_profiled=7]
+FETCH_SIZE / WRITE_SIZE are in KiB per dispatch; per MI355X_MICROARCH.md §HBM, FETCH_SIZE on gfx950
+reports exactly half of the bytes of a wide coalesced streaming read, so the read side is doubled.
+"""
+import csv, glob, os, shutil, sys, collections
+
+src, tag = sys.argv[1], sys.argv[2]
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+os.makedirs("profiles", exist_ok=True)
+stats = glob.glob(f"{src}/stats/*/*kernel_stats.csv")[0]
+shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
+rows = list(csv.DictReader(open(stats)))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+
+
+def short(n):
+    return n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+def pmc(kind):
+    f = glob.glob(f"{src}/pmc_{kind}/*/*counter_collection.csv")
+    if not f:
+        return {}
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f[0])):
+        k = short(r["Kernel_Name"])
+        acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+    return {k: v[0] / v[1] for k, v in acc.items()}
+
+
+fetch, write = pmc("fetch"), pmc("write")
+lines = [f"# rocprofv3 summary `{tag}` — bench.py --steps 5 --warmup 2 (N=1, batch 64, SR2, fp32)", "",
+         f"Total kernel time {tot/1e6:.1f} ms over {steps} steps = **{tot/1e6/steps:.2f} ms/step**.", "",
+         "| kernel | calls | avg µs | ms/step | % | HBM read MB/launch (2×FETCH_SIZE) | HBM write MB/launch |", "|---|---|---|---|---|---|---|"]
+for r in rows[:30]:
+    k = short(r["Name"])
+    fr = fetch.get(k); wr = write.get(k)
+    lines.append("| `%s` | %s | %.1f | %.3f | %.1f | %s | %s |" % (
+        k[:58], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6 / steps,
+        100 * float(r["TotalDurationNs"]) / tot,
+        "%.1f" % (2 * fr * 1024 / 1e6) if fr is not None else "", "%.1f" % (wr * 1024 / 1e6) if wr is not None else ""))
+open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
