@@ -107,7 +107,7 @@ int sifsr_conv3x3_wgrad(const float* src0, int C0, const float* scale0, const fl
   if (nblk > a.ntiles) nblk = a.ntiles;
   int rc = launch_conv3x3_wgrad(a, cin, cout, nblk, S(stream));
   if (rc) return rc;
-  return launch_wgrad_reduce(scratch, nblk, cin, cout, dw, S(stream));
+  return launch_wgrad_reduce(scratch, nblk, cin, cout, wgrad_nbi_chunk(a, cin), dw, S(stream));
 }
 
 int sifsr_conv_in_fwd(const float* x, const float* w, float* y, float* stat_partials, int B, int H, int W, void* stream) {

@@ -48,7 +48,8 @@ struct WgradArgs {
 };
 // returns the number of slab blocks used through *nblk_out
 int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s);
-int launch_wgrad_reduce(const float* slabs, int nblk, int cin, int cout, float* dw_oihw, hipStream_t s);
+int wgrad_nbi_chunk(const WgradArgs& a, int cin);   // 16-channel blocks per Cin chunk (blockIdx.y)
+int launch_wgrad_reduce(const float* slabs, int nblk, int cin, int cout, int nbi_chunk, float* dw_oihw, hipStream_t s);
 size_t wgrad_slab_floats(int cin, int cout);   // floats per block
 
 // dgrad: replicate-padding adjoint fold for the border pixels (adds to g_in).  wdg_layer = the layer's

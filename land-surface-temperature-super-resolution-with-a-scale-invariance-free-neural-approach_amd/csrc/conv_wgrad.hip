@@ -19,13 +19,26 @@ constexpr int WPW = 18, WPH = WT_ROWS + 2; // halo tile
 constexpr int WPIX_IN = WPW * WPH;         // 180
 constexpr int WPIX_OUT = 16 * WT_ROWS;     // 128
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+static __device__ __forceinline__ float4 wg_bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 template <int NBO, int NBI>   // cout blocks, cin blocks handled by one workgroup (cin chunk = blockIdx.y)
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, const int lgx, const int lgy) {
   constexpr int WO = NBO >= 2 ? 2 : 1, WI = NBI >= 2 ? 2 : 1, WP = 4 / (WO * WI);
   constexpr int NBO_W = NBO / WO, NBI_W = NBI / WI;
   constexpr int CSO = NBO * 16 + (NBO % 2 == 0 ? 16 : 0);   // = 16 mod 32
   constexpr int CSI = NBI * 16 + (NBI % 2 == 0 ? 16 : 0);
   constexpr int NT = NBO_W * NBI_W * 9;                       // accumulator tiles per wave
+  constexpr int QO = NBO * 4, QI = NBI * 4;                   // channel quads per pixel (dy / input chunk)
+  constexpr int PPO = 256 / QO, PPI = 256 / QI;               // pixels staged per pass by the workgroup
+  constexpr int NIO = WPIX_OUT / PPO;                         // prefetch float4s per thread, dy tile
+  constexpr int NII = (WPIX_IN + PPI - 1) / PPI;              // ... input halo tile (last pass partial)
 
   __shared__ float smem[WPIX_OUT * CSO + WPIX_IN * CSI];
   float* const lds_dy = smem;
@@ -37,7 +50,37 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
   const int H = a.H, W = a.W;
   const int tiles_x = W / 16, tiles_y = H / WT_ROWS;
   const int q0 = blockIdx.y * NBI;   // first 16-channel block of my cin chunk
-  const int Cout = NBO * 16;
+  constexpr int Cout = NBO * 16;
+  const unsigned npix = (unsigned)a.B * (unsigned)H * (unsigned)W;
+
+  // the cin chunk lies entirely in one of the two concatenated sources (chunks are <= 32 channels)
+  const bool first = q0 < a.src[0].nq;
+  const ConvSrc& src = first ? a.src[0] : a.src[1];
+  const int ch0 = src.coff + 16 * (first ? q0 : q0 - a.src[0].nq);
+  const int lgc = 31 - __builtin_clz((unsigned)src.C) + 2;                 // log2(C * 4 bytes)
+  const __amdgpu_buffer_rsrc_t rin = wg_rsrc(src.ptr, npix * (unsigned)src.C * 4u);
+  const __amdgpu_buffer_rsrc_t rdy = wg_rsrc(a.dy, npix * (unsigned)Cout * 4u);
+
+  // ---- per-thread staging constants (tile independent) ----
+  const int c4o = tid % QO, po0 = tid / QO;      // dy: pixel po0 + i*PPO, channels 4*c4o..
+  const int c4i = tid % QI, pi0 = tid / QI;      // input halo: pixel pi0 + i*PPI
+  unsigned vo_dy[NIO];
+#pragma unroll
+  for (int i = 0; i < NIO; ++i) {
+    const int p = po0 + i * PPO;
+    vo_dy[i] = (unsigned)(((p >> 4) * W + (p & 15)) * Cout * 4 + c4o * 16);
+  }
+  int ipy[NII], ipx[NII];
+#pragma unroll
+  for (int i = 0; i < NII; ++i) {
+    int p = pi0 + i * PPI;
+    if (p >= WPIX_IN) p = WPIX_IN - 1;
+    ipy[i] = p / WPW;
+    ipx[i] = p - ipy[i] * WPW;
+  }
+  float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool raw = src.scale == nullptr;
+  if (!raw) { psc = ld4(src.scale + ch0 + 4 * c4i); psh = ld4(src.shift + ch0 + 4 * c4i); }
 
   f32x4 acc[NBO_W][NBI_W][9];
 #pragma unroll
@@ -47,34 +90,52 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) acc[o][i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-    const int x0 = tx * 16, y0 = ty * WT_ROWS;
-    __syncthreads();
-    // ---- stage dy tile: 128 pixels x Cout, float4 granules ----
-    for (int e = tid; e < WPIX_OUT * (Cout / 4); e += 256) {
-      const int c4 = e % (Cout / 4), p = e / (Cout / 4);
-      const int py = p >> 4, px = p & 15;
-      const float4 v = ld4(a.dy + ((size_t)(b * H + y0 + py) * W + x0 + px) * Cout + 4 * c4);
-      *reinterpret_cast<float4*>(&lds_dy[p * CSO + 4 * c4]) = v;
+  float4 pdy[NIO], pin[NII];
+  auto issue = [&](int tile) {
+    int txi, tyi, b;
+    if (lgx >= 0) { txi = tile & (tiles_x - 1); tyi = (tile >> lgx) & (tiles_y - 1); b = tile >> (lgx + lgy); }
+    else { txi = tile % tiles_x; const int r = tile / tiles_x; tyi = r % tiles_y; b = r / tiles_y; }
+    const int x0 = txi * 16, y0 = tyi * WT_ROWS;
+    const unsigned base = (unsigned)((b * H + y0) * W + x0);
+#pragma unroll
+    for (int i = 0; i < NIO; ++i) pdy[i] = wg_bload4(rdy, vo_dy[i], base * (unsigned)(Cout * 4));
+    const bool interior = txi > 0 && tyi > 0 && txi + 1 < tiles_x && tyi + 1 < tiles_y;
+    const unsigned chb = (unsigned)(ch0 + 4 * c4i) * 4u;
+    if (interior) {
+      const unsigned soff = ((base - (unsigned)W - 1u) << lgc);
+#pragma unroll
+      for (int i = 0; i < NII; ++i) pin[i] = wg_bload4(rin, ((unsigned)(ipy[i] * W + ipx[i]) << lgc) + chb, soff);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NII; ++i) {
+        const int gy = clampi(y0 - 1 + ipy[i], 0, H - 1), gx = clampi(x0 - 1 + ipx[i], 0, W - 1);
+        pin[i] = wg_bload4(rin, ((unsigned)((b * H + gy) * W + gx) << lgc) + chb, 0u);
+      }
     }
-    // ---- stage a_in halo tile (replicate clamp) with the producer's BN+ReLU folded in ----
-    for (int e = tid; e < WPIX_IN * (NBI * 4); e += 256) {
-      const int c4 = e % (NBI * 4), p = e / (NBI * 4);
-      const int py = p / WPW, px = p - py * WPW;
-      const int gy = clampi(y0 - 1 + py, 0, H - 1), gx = clampi(x0 - 1 + px, 0, W - 1);
-      const int q = q0 + (c4 >> 2);
-      const bool first = q < a.src[0].nq;
-      const ConvSrc& s = first ? a.src[0] : a.src[1];
-      const int ch = s.coff + 16 * (first ? q : q - a.src[0].nq) + 4 * (c4 & 3);
-      float4 v = ld4(s.ptr + ((size_t)(b * H + gy) * W + gx) * s.C + ch);
-      if (s.scale != nullptr) v = bn_relu4(v, ld4(s.scale + ch), ld4(s.shift + ch));
-      *reinterpret_cast<float4*>(&lds_in[p * CSI + 4 * c4]) = v;
-    }
-    __syncthreads();
+  };
 
-    const int i16 = lane & 15, k = lane >> 4;
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) issue(tile);
+  const int i16 = lane & 15, k = lane >> 4;
+
+  while (tile < a.ntiles) {
+    __syncthreads();          // previous tile's MFMA reads are done
+#pragma unroll
+    for (int i = 0; i < NIO; ++i)
+      *reinterpret_cast<float4*>(&lds_dy[(po0 + i * PPO) * CSO + 4 * c4o]) = pdy[i];
+#pragma unroll
+    for (int i = 0; i < NII; ++i) {
+      const int p = pi0 + i * PPI;
+      float4 v = pin[i];
+      if (!raw) v = bn_relu4(v, psc, psh);
+      if (i + 1 < NII || p < WPIX_IN) *reinterpret_cast<float4*>(&lds_in[p * CSI + 4 * c4i]) = v;
+    }
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < a.ntiles) issue(next);     // in flight during the MFMA phase below
+
     // k-steps: (row r, pixel quad qd); this wave takes every WP-th one
+#pragma unroll 2
     for (int ks = wp; ks < WT_ROWS * 4; ks += WP) {
       const int r = ks >> 2, qd = ks & 3;
       float av[NBO_W];
@@ -95,6 +156,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
             acc[o][i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[o], bv[i], acc[o][i][t], 0, 0, 0);
       }
     }
+    tile = next;
   }
 
   // ---- combine the WP pixel-split waves through LDS, then write the slab ----
@@ -176,7 +238,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 template <int NBO, int NBI>
 int launch_wgrad_t(const WgradArgs& a, int chunks, int nblk, hipStream_t s) {
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<NBO, NBI>), dim3(nblk, chunks), dim3(256), 0, s, a);
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+  const int tx_ = a.W / 16, ty_ = a.H / WT_ROWS;
+  const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<NBO, NBI>), dim3(nblk, chunks), dim3(256), 0, s, a, lgx, lgy);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
@@ -185,22 +251,36 @@ int launch_wgrad_t(const WgradArgs& a, int chunks, int nblk, hipStream_t s) {
 
 size_t wgrad_slab_floats(int cin, int cout) { return (size_t)9 * cin * cout; }
 
-// Cin is processed in chunks of <= 32 channels (blockIdx.y): keeps LDS <= 76 KB so two workgroups fit a CU
-static int wgrad_nbi_chunk(int cin) { return cin >= 32 ? 2 : 1; }
+// Cin is processed in chunks of <= 32 channels (blockIdx.y): keeps LDS <= 76 KB so two workgroups fit a CU.
+// A chunk never straddles the two concatenated sources (16-channel chunks when the first has an odd
+// number of 16-channel blocks, e.g. ub3.convbloc.bloc.0 = cat(16, 16)).
+int wgrad_nbi_chunk(const WgradArgs& a, int cin) {
+  if (cin < 32) return 1;
+  if (a.src[1].ptr != nullptr && (a.src[0].nq % 2)) return 1;
+  return 2;
+}
 
 int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s) {
   if (a.H % WT_ROWS || a.W % 16 || cin % 16 || cout % 16 || nblk < 1) return SIFSR_ERR_SHAPE;
-  const int nbi = wgrad_nbi_chunk(cin), chunks = (cin / 16) / nbi, nbo = cout / 16;
+  {
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    const size_t npix = (size_t)a.B * a.H * a.W;
+    int cmax = a.src[0].C > a.src[1].C ? a.src[0].C : a.src[1].C;
+    cmax = cmax > cout ? cmax : cout;
+    if (npix * cmax * 4 >= ((size_t)1 << 32) - 4096) return SIFSR_ERR_SHAPE;      // 32-bit buffer offsets
+    if (!pow2(a.src[0].C) || (a.src[1].ptr && !pow2(a.src[1].C))) return SIFSR_ERR_SHAPE;
+  }
+  const int nbi = wgrad_nbi_chunk(a, cin), chunks = (cin / 16) / nbi, nbo = cout / 16;
 #define SIFSR_WG(NBOV, NBIV) if (nbo == NBOV && nbi == NBIV) return launch_wgrad_t<NBOV, NBIV>(a, chunks, nblk, s);
   SIFSR_WG(1, 1) SIFSR_WG(1, 2) SIFSR_WG(2, 1) SIFSR_WG(2, 2) SIFSR_WG(4, 2)
 #undef SIFSR_WG
   return SIFSR_ERR_SHAPE;
 }
 
-int launch_wgrad_reduce(const float* slabs, int nblk, int cin, int cout, float* dw_oihw, hipStream_t s) {
+int launch_wgrad_reduce(const float* slabs, int nblk, int cin, int cout, int nbi_chunk, float* dw_oihw, hipStream_t s) {
   const int n = 9 * cin * cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, slabs, nblk, cin, cout,
-                     wgrad_nbi_chunk(cin), dw_oihw);
+                     nbi_chunk, dw_oihw);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

@@ -49,13 +49,11 @@ const NetTable& sifsr_net() {
 // ---------------------------------------------------------------------------------------------
 static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }   // in floats (256 B)
 
-static int wgrad_blocks(int cin, int cout, int ntiles) {
-  // persistent workgroups; blockIdx.y additionally splits Cin into 32-channel chunks.  Enough of them to
-  // fill every CU several times over (the slab each one writes is 9*cin*cout floats / chunk count).
-  const size_t slab = (size_t)9 * cin * cout;
-  const int cap = slab <= 4608 ? 2048 : (slab <= 18432 ? 1024 : 512);
-  const int chunks = cin >= 64 ? cin / 32 : 1;
-  int n = cap / chunks;
+static int wgrad_blocks(int chunks, int ntiles) {
+  // persistent, software-pipelined workgroups: about two per CU are resident (LDS / VGPR), so launch about
+  // that many (x the Cin chunks in blockIdx.y); fewer slabs also make the slab reduction cheaper.
+  int n = 512 / chunks;
+  if (n < 128) n = 128;
   return ntiles < n ? ntiles : n;
 }
 
@@ -98,7 +96,7 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
     size_t maxslab = 1024 * 288;   // edge-layer partials
     for (int l = 1; l < SIFSR_NUM_BN_LAYERS; ++l) {
       const int ntiles = (int)(N[nt.L[l].level] / 128);
-      const size_t n = (size_t)wgrad_blocks(nt.L[l].cin, nt.L[l].cout, ntiles) * 9 * nt.L[l].cin * nt.L[l].cout;
+      const size_t n = (size_t)wgrad_blocks(1, ntiles) * 9 * nt.L[l].cin * nt.L[l].cout;   // upper bound over chunkings
       maxslab = n > maxslab ? n : maxslab;
     }
     w.slabs = take(maxslab);
@@ -208,12 +206,13 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
   a.B = c.B; a.H = c.lvH(L.level); a.W = c.lvW(L.level);
   a.NQ = L.cin / 16;
   a.ntiles = c.B * (a.H / 8) * (a.W / 16);
-  const int nblk = wgrad_blocks(L.cin, L.cout, a.ntiles);
+  const int nbi = wgrad_nbi_chunk(a, L.cin);
+  const int nblk = wgrad_blocks(L.cin / (16 * nbi), a.ntiles);
   {
     ProfScope ps(l, 3, c.s);
     SIFSR_TRY(launch_conv3x3_wgrad(a, L.cin, L.cout, nblk, c.s));
   }
-  SIFSR_TRY(launch_wgrad_reduce(a.slabs, nblk, L.cin, L.cout, grads + L.w_off, c.s));
+  SIFSR_TRY(launch_wgrad_reduce(a.slabs, nblk, L.cin, L.cout, nbi, grads + L.w_off, c.s));
   return SIFSR_OK;
 }
 
