@@ -337,8 +337,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
 // One thread per (border pixel, 4 input channels); weights tap-major so the ci quad is one float4.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void border_accum(float4& acc, const float* __restrict__ d, const float* __restrict__ wt,
-                                             int Cout, int Cin) {
-  for (int co = 0; co < Cout; co += 4) {
+                                             int co_lo, int co_hi, int Cin) {
+#pragma unroll 2
+  for (int co = co_lo; co < co_hi; co += 4) {
     const float4 dv = ld4(d + co);
     const float4 w0 = ld4(wt + (size_t)(co + 0) * Cin), w1 = ld4(wt + (size_t)(co + 1) * Cin);
     const float4 w2 = ld4(wt + (size_t)(co + 2) * Cin), w3 = ld4(wt + (size_t)(co + 3) * Cin);
@@ -376,9 +377,9 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
       const bool bx = qx - tx >= 0 && qx - tx < W;
       if (!ey && !ex) continue;
       const float* wt = wb + ((size_t)((ty + 1) * 3 + (tx + 1)) * Cout) * Cin + 4 * c4;
-      if (ey && bx) border_accum(acc, img + ((size_t)qy * W + (qx - tx)) * Cout, wt, Cout, Cin);
-      if (by && ex) border_accum(acc, img + ((size_t)(qy - ty) * W + qx) * Cout, wt, Cout, Cin);
-      if (ey && ex) border_accum(acc, img + ((size_t)qy * W + qx) * Cout, wt, Cout, Cin);
+      if (ey && bx) border_accum(acc, img + ((size_t)qy * W + (qx - tx)) * Cout, wt, 0, Cout, Cin);
+      if (by && ex) border_accum(acc, img + ((size_t)(qy - ty) * W + qx) * Cout, wt, 0, Cout, Cin);
+      if (ey && ex) border_accum(acc, img + ((size_t)qy * W + qx) * Cout, wt, 0, Cout, Cin);
     }
   }
   const size_t pix = (size_t)(b * H + qy) * W + qx;

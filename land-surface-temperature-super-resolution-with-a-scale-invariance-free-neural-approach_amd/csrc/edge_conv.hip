@@ -60,22 +60,26 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
   }
 }
 
-// input conv weight gradient: dW[co][ci][t] = sum dy[p][co] * x[clamp(p+t)][ci]; 288 outputs.
-// persistent workgroups, per-workgroup partial [288], summed by sum_partials_kernel.
+// input conv weight gradient: dW[co][ci][t] = sum_p dy[p][co] * x[clamp(p+t)][ci]  (288 outputs) on the
+// matrix cores: M = co (16), N = n = ci*9+t (18, padded to two 16-wide tiles), K = pixels.
+//   A lane (i = co, k = pixel)  <- dy tile [256 px][16]        (conflict-free: pixel stride 16 floats)
+//   B lane (j = n,  k = pixel)  <- x halo planes at a per-lane constant (ci, tap) offset
+// Persistent workgroups; each wave takes every 4th k-step; partial [blk][288] summed by sum_partials_kernel.
 __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ partials, int B, int H, int W) {
-  __shared__ float tile[2][18 * 18];
+  __shared__ float tile[2 * 324 + 8];
   __shared__ float dyt[256 * 16];
-  const int tid = threadIdx.x;
+  __shared__ float red[4][2][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = W / 16, tiles_y = H / 16, ntiles = B * tiles_x * tiles_y;
-  // thread -> outputs e0 = tid and e1 = tid + 256 (< 288); e = co*18 + ci*9 + t
-  const int e0 = tid, e1 = tid + 256;
-  const bool has1 = e1 < 288;
-  const int co0 = e0 / 18, k0 = e0 % 18, co1 = has1 ? e1 / 18 : 0, k1 = has1 ? e1 % 18 : 0;
-  const int off0 = (k0 % 9) / 3 * 18 + (k0 % 9) % 3, off1 = (k1 % 9) / 3 * 18 + (k1 % 9) % 3;
-  const float* t0 = tile[k0 / 9];
-  const float* t1 = tile[k1 / 9];
-  float a0 = 0.f, a1 = 0.f;
+  const int i16 = lane & 15, k = lane >> 4;
+  int offn[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = nt * 16 + i16;
+    offn[nt] = n < 18 ? (n / 9) * 324 + ((n % 9) / 3) * 18 + (n % 9) % 3 : 0;   // n >= 18: columns never stored
+  }
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
   for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
     const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, b = tl / (tiles_x * tiles_y);
     const int x0 = tx * 16, y0 = ty * 16;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restr
       const int c = e / 324, p = e - c * 324;
       const int py = p / 18, px = p - py * 18;
       const int gy = clampi(y0 - 1 + py, 0, H - 1), gx = clampi(x0 - 1 + px, 0, W - 1);
-      tile[c][p] = x[((size_t)(b * 2 + c) * H + gy) * W + gx];
+      tile[e] = x[((size_t)(b * 2 + c) * H + gy) * W + gx];
     }
     for (int e = tid; e < 256 * 4; e += 256) {
       const int p = e >> 2, c4 = e & 3;
@@ -92,14 +96,27 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restr
           ld4(dy + ((size_t)(b * H + y0 + (p >> 4)) * W + x0 + (p & 15)) * 16 + 4 * c4);
     }
     __syncthreads();
-    for (int p = 0; p < 256; ++p) {
-      const int base = (p >> 4) * 18 + (p & 15);
-      a0 = fmaf(dyt[p * 16 + co0], t0[base + off0], a0);
-      if (has1) a1 = fmaf(dyt[p * 16 + co1], t1[base + off1], a1);
+#pragma unroll 4
+    for (int ks = wave; ks < 64; ks += 4) {
+      const int r = ks >> 2, qd = ks & 3;
+      const float av = dyt[(r * 16 + 4 * qd + k) * 16 + i16];
+      const int base = r * 18 + 4 * qd + k;
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tile[offn[0] + base], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tile[offn[1] + base], acc[1], 0, 0, 0);
     }
   }
-  partials[(size_t)blockIdx.x * 288 + e0] = a0;
-  if (has1) partials[(size_t)blockIdx.x * 288 + e1] = a1;
+  // D[row = co = 4*(lane>>4) + r][col = n]  ->  red[wave][nt][co*16 + col]; sum the 4 waves; e = co*18 + n
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][nt][(4 * k + r) * 16 + i16] = acc[nt][r];
+  __syncthreads();
+  for (int e = tid; e < 288; e += 256) {
+    const int co = e / 18, n = e % 18;
+    const int nt = n >> 4, col = n & 15;
+    partials[(size_t)blockIdx.x * 288 + e] =
+        red[0][nt][co * 16 + col] + red[1][nt][co * 16 + col] + red[2][nt][co * 16 + col] + red[3][nt][co * 16 + col];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -182,31 +199,61 @@ __global__ __launch_bounds__(256) void conv_out_dgrad_kernel(const float* __rest
   }
 }
 
-// output conv weight/bias gradient: dW[ci][t] = sum dsr[p] * a[clamp(p+t)][ci]; db = sum dsr. 145 outputs.
+// output conv weight/bias gradient: dW[ci][t] = sum_p dsr[p] * a[clamp(p+t)][ci]; db = sum dsr (145 outputs).
+// On the matrix cores with the HALO pixel p' = p + t as contraction index, so the A operand does not depend
+// on the tap:  D[ci][t] = sum_{p'} a[p'][ci] * dsr[p' - t]   (dsr = 0 outside the 16x16 tile).
+//   A lane (i = ci, k = pixel) <- a halo tile [18 rows][20 cols (2 zero pad)][OCS]
+//   B lane (j = t,  k = pixel) <- dsr tile at the per-lane tap shift
 __global__ __launch_bounds__(256) void conv_out_wgrad_kernel(const float* __restrict__ y, const float* scale,
                                                              const float* shift, const float* __restrict__ dsr,
                                                              float* __restrict__ partials, int B, int H, int W) {
-  __shared__ float tile[324 * OCS];
+  __shared__ float tile[18 * 20 * OCS];
   __shared__ float dt[256];
-  const int tid = threadIdx.x;
+  __shared__ float red[4][256];
+  __shared__ float bsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = W / 16, tiles_y = H / 16, ntiles = B * tiles_x * tiles_y;
-  const int ci = tid / 9, t = tid % 9;
-  const int off = ((t / 3) * 18 + t % 3) * OCS + (tid < 144 ? ci : 0);
-  float acc = 0.f;
+  const int i16 = lane & 15, k = lane >> 4;
+  const int tty = i16 < 9 ? i16 / 3 : 100, ttx = i16 < 9 ? i16 % 3 : 100;   // lanes j >= 9: always out of range -> 0
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bacc = 0.f;
+  for (int e = tid; e < 18 * 20 * OCS; e += 256) tile[e] = 0.f;     // pad columns 18,19 stay zero
   for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
     const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, b = tl / (tiles_x * tiles_y);
     const int x0 = tx * 16, y0 = ty * 16;
     __syncthreads();
-    stage_out_tile(tile, y, scale, shift, b, y0, x0, H, W, tid);
-    dt[tid] = dsr[(size_t)(b * H + y0 + (tid >> 4)) * W + x0 + (tid & 15)];
+    for (int e = tid; e < 324 * 4; e += 256) {
+      const int p = e >> 2, c4 = e & 3;
+      const int py = p / 18, px = p - py * 18;
+      const int gy = clampi(y0 - 1 + py, 0, H - 1), gx = clampi(x0 - 1 + px, 0, W - 1);
+      float4 v = ld4(y + ((size_t)(b * H + gy) * W + gx) * 16 + 4 * c4);
+      if (scale != nullptr) v = bn_relu4(v, ld4(scale + 4 * c4), ld4(shift + 4 * c4));
+      *reinterpret_cast<float4*>(&tile[(py * 20 + px) * OCS + 4 * c4]) = v;
+    }
+    const float dv = dsr[(size_t)(b * H + y0 + (tid >> 4)) * W + x0 + (tid & 15)];
+    dt[tid] = dv;
+    bacc += dv;
     __syncthreads();
-    if (tid < 144) {
-      for (int p = 0; p < 256; ++p) acc = fmaf(dt[p], tile[((p >> 4) * 18 + (p & 15)) * OCS + off], acc);
-    } else if (tid == 144) {
-      for (int p = 0; p < 256; ++p) acc += dt[p];
+    for (int ks = wave; ks < 90; ks += 4) {          // 18 rows x 5 quads of the padded halo tile
+      const int row = ks / 5, col = (ks - row * 5) * 4 + k;
+      const float av = tile[(row * 20 + col) * OCS + i16];
+      const int oy = row - tty, ox = col - ttx;
+      const float bv = (oy >= 0 && oy < 16 && ox >= 0 && ox < 16) ? dt[oy * 16 + ox] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
     }
   }
-  if (tid < 145) partials[(size_t)blockIdx.x * 145 + tid] = acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][(4 * k + r) * 16 + i16] = acc[r];   // [ci][t]
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) bacc += __shfl_xor(bacc, m);
+  if (lane == 0) bsum[wave] = bacc;
+  __syncthreads();
+  if (tid < 144) {
+    const int ci = tid / 9, t = tid % 9;
+    partials[(size_t)blockIdx.x * 145 + tid] = red[0][ci * 16 + t] + red[1][ci * 16 + t] + red[2][ci * 16 + t] + red[3][ci * 16 + t];
+  } else if (tid == 144) {
+    partials[(size_t)blockIdx.x * 145 + 144] = bsum[0] + bsum[1] + bsum[2] + bsum[3];
+  }
 }
 
 // out[e] = sum_k partials[k][e] in float64, fixed order (deterministic): 32 outputs x 8 row groups per block
