@@ -336,58 +336,91 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
 // (q = N-1, t = +1); the 2-D set is the product of the per-axis sets minus the (base, base) pair.
 // One thread per (border pixel, 4 input channels); weights tap-major so the ci quad is one float4.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void border_accum(float4& acc, const float* __restrict__ d, const float* __restrict__ wt,
-                                             int co_lo, int co_hi, int Cin) {
-#pragma unroll 2
-  for (int co = co_lo; co < co_hi; co += 4) {
-    const float4 dv = ld4(d + co);
-    const float4 w0 = ld4(wt + (size_t)(co + 0) * Cin), w1 = ld4(wt + (size_t)(co + 1) * Cin);
-    const float4 w2 = ld4(wt + (size_t)(co + 2) * Cin), w3 = ld4(wt + (size_t)(co + 3) * Cin);
-    acc.x = fmaf(dv.x, w0.x, acc.x); acc.y = fmaf(dv.x, w0.y, acc.y); acc.z = fmaf(dv.x, w0.z, acc.z); acc.w = fmaf(dv.x, w0.w, acc.w);
-    acc.x = fmaf(dv.y, w1.x, acc.x); acc.y = fmaf(dv.y, w1.y, acc.y); acc.z = fmaf(dv.y, w1.z, acc.z); acc.w = fmaf(dv.y, w1.w, acc.w);
-    acc.x = fmaf(dv.z, w2.x, acc.x); acc.y = fmaf(dv.z, w2.y, acc.y); acc.z = fmaf(dv.z, w2.z, acc.z); acc.w = fmaf(dv.z, w2.w, acc.w);
-    acc.x = fmaf(dv.w, w3.x, acc.x); acc.y = fmaf(dv.w, w3.y, acc.y); acc.z = fmaf(dv.w, w3.z, acc.z); acc.w = fmaf(dv.w, w3.w, acc.w);
-  }
-}
-
+// One WAVE per (image, side, 16-pixel border segment, 16 input channels):
+//   D[ci][pixel] += sum over (tap, source) pairs of  Wd_tap[ci][co] * dy[source(pixel)][co]
+// with v_mfma_f32_16x16x4_f32: A = fragment-ordered dgrad weights (same pack as the main kernel; tap index
+// flipped: forward tap t <-> pack index 8 - t), B = dy rows gathered straight from global (one float4 per lane
+// = 4 k-steps), no LDS, no barrier.  Pairs per side (forward tap (ty,tx), source p; q = border pixel):
+//   top    (qy=0)   : ((-1,tx), (0, qx-tx)) tx=-1..1 ;  bottom (qy=H-1): ((+1,tx), (H-1, qx-tx))
+//   left   (qx=0,   1<=qy<=H-2): ((ty,-1), (qy-ty, 0)) ; right (qx=W-1): ((ty,+1), (qy-ty, W-1))
+//   corners belong to the top/bottom passes and add, on the corner lane only,
+//     top-left: ((0,-1),(0,0)), ((-1,-1),(1,0)+(0,0))      top-right: ((0,+1),(0,W-1)), ((-1,+1),(1,W-1)+(0,W-1))
+//     bottom-left: ((0,-1),(H-1,0)), ((+1,-1),(H-2,0)+(H-1,0))   bottom-right: mirrored.
 __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restrict__ dy, int Cout,
-                                                           const float* __restrict__ wb, int Cin, float* g0, int C0,
+                                                           const float* __restrict__ wd, int Cin, float* g0, int C0,
                                                            int split_ch, float* g1, int C1, int B, int H, int W) {
-  const int Q = Cin / 4;
-  const int per_img = 2 * W + 2 * (H - 2);
-  const int total = B * per_img * Q;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int c4 = e % Q;
-  const int bp = (e / Q) % per_img;
-  const int b = e / (Q * per_img);
-  int qy, qx;
-  if (bp < W) { qy = 0; qx = bp; }
-  else if (bp < 2 * W) { qy = H - 1; qx = bp - W; }
-  else { const int r = bp - 2 * W; qy = 1 + (r >> 1); qx = (r & 1) ? W - 1 : 0; }
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int NBI = Cin / 16, NQ = Cout / 16;
+  const int seg_tb = W / 16, seg_lr = (H - 2 + 15) / 16;
+  const int per_img = (2 * seg_tb + 2 * seg_lr) * NBI;
+  if (wave_g >= B * per_img) return;                       // wave-uniform
+  const int b = wave_g / per_img;
+  int r = wave_g - b * per_img;
+  const int nb = r % NBI; r /= NBI;
+  int side, seg;                                           // 0 top, 1 bottom, 2 left, 3 right
+  if (r < 2 * seg_tb) { side = r / seg_tb; seg = r - side * seg_tb; }
+  else { r -= 2 * seg_tb; side = 2 + r / seg_lr; seg = r % seg_lr; }
+  const int px = lane & 15, kq = lane >> 4;
   const float* img = dy + (size_t)b * H * W * Cout;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* wbase = wd + (size_t)nb * NQ * 9 * 256 + lane * 4;       // wd[nb][q][tap'][lane][4]
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto mac = [&](int tp_fwd, int q, float4 bv) {           // forward tap index tp_fwd = (ty+1)*3 + (tx+1)
+    const float4 w = ld4(wbase + ((size_t)q * 9 + (8 - tp_fwd)) * 256);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, bv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, bv.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, bv.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, bv.w, acc, 0, 0, 0);
+  };
+  auto row = [&](int y, int x, int q) { return ld4(img + ((size_t)y * W + x) * Cout + 16 * q + 4 * kq); };
+
+  int qy, qx;
+  bool valid = true;
+  if (side < 2) {
+    qy = side == 0 ? 0 : H - 1; qx = seg * 16 + px;
+    const int ty = side == 0 ? -1 : 1;
+    const int yin = side == 0 ? 1 : H - 2;                  // the row next to the border row
+    for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-  for (int ty = -1; ty <= 1; ++ty) {
-    const bool ey = (qy == 0 && ty == -1) || (qy == H - 1 && ty == 1);      // extra source row = qy
-    const bool by = qy - ty >= 0 && qy - ty < H;                            // base source row in range
+      for (int tx = -1; tx <= 1; ++tx) {
+        const int sx = qx - tx;
+        mac((ty + 1) * 3 + (tx + 1), q, (sx >= 0 && sx < W) ? row(qy, sx, q) : z4);
+      }
+      if (seg == 0) {                                       // left corner lane (qx == 0): taps (0,-1) and (ty,-1)
+        const bool c = qx == 0;
+        const float4 e = row(qy, 0, q), n = row(yin, 0, q);
+        mac(1 * 3 + 0, q, c ? e : z4);
+        mac((ty + 1) * 3 + 0, q, c ? make_float4(e.x + n.x, e.y + n.y, e.z + n.z, e.w + n.w) : z4);
+      }
+      if (seg == seg_tb - 1) {                              // right corner lane (qx == W-1): taps (0,+1) and (ty,+1)
+        const bool c = qx == W - 1;
+        const float4 e = row(qy, W - 1, q), n = row(yin, W - 1, q);
+        mac(1 * 3 + 2, q, c ? e : z4);
+        mac((ty + 1) * 3 + 2, q, c ? make_float4(e.x + n.x, e.y + n.y, e.z + n.z, e.w + n.w) : z4);
+      }
+    }
+  } else {
+    qx = side == 2 ? 0 : W - 1; qy = 1 + seg * 16 + px;
+    valid = qy <= H - 2;
+    const int tx = side == 2 ? -1 : 1;
+    const int yc = valid ? qy : H - 2;
+    for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-    for (int tx = -1; tx <= 1; ++tx) {
-      const bool ex = (qx == 0 && tx == -1) || (qx == W - 1 && tx == 1);
-      const bool bx = qx - tx >= 0 && qx - tx < W;
-      if (!ey && !ex) continue;
-      const float* wt = wb + ((size_t)((ty + 1) * 3 + (tx + 1)) * Cout) * Cin + 4 * c4;
-      if (ey && bx) border_accum(acc, img + ((size_t)qy * W + (qx - tx)) * Cout, wt, 0, Cout, Cin);
-      if (by && ex) border_accum(acc, img + ((size_t)(qy - ty) * W + qx) * Cout, wt, 0, Cout, Cin);
-      if (ey && ex) border_accum(acc, img + ((size_t)qy * W + qx) * Cout, wt, 0, Cout, Cin);
+      for (int ty = -1; ty <= 1; ++ty)
+        mac((ty + 1) * 3 + (tx + 1), q, valid ? row(yc - ty, qx, q) : z4);
     }
   }
-  const size_t pix = (size_t)(b * H + qy) * W + qx;
-  const int ci = 4 * c4;
-  float* dst = ci < split_ch ? g0 + pix * C0 + ci : g1 + pix * C1 + (ci - split_ch);
-  float4 v = ld4(dst);
-  v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
-  st4(dst, v);
+  if (valid) {
+    // D rows = ci 4*kq + r, col = pixel  ->  one float4 read-modify-write per lane
+    const size_t pix = (size_t)(b * H + qy) * W + qx;
+    const int ci = 16 * nb + 4 * kq;
+    float* dst = ci < split_ch ? g0 + pix * C0 + ci : g1 + pix * C1 + (ci - split_ch);
+    float4 v = ld4(dst);
+    v.x += acc[0]; v.y += acc[1]; v.z += acc[2]; v.w += acc[3];
+    st4(dst, v);
+  }
 }
 
 }  // namespace
@@ -470,9 +503,9 @@ int launch_pack_weights_one(const float* w, int cin, int cout, float* wfwd, floa
 
 int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, int Cin, float* g0, int C0,
                             int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s) {
-  const int total = B * (2 * W + 2 * (H - 2)) * (Cin / 4);
-  const float* wb = wdg_layer + (size_t)9 * Cin * Cout;   // tap-major copy behind the fragment-ordered one
-  hipLaunchKernelGGL(dgrad_border_kernel, dim3((total + 255) / 256), dim3(256), 0, s, dy, Cout, wb, Cin, g0, C0,
+  if (H < 3 || W % 16 || Cin % 16 || Cout % 16) return SIFSR_ERR_SHAPE;
+  const int waves = B * (2 * (W / 16) + 2 * ((H - 2 + 15) / 16)) * (Cin / 16);
+  hipLaunchKernelGGL(dgrad_border_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, dy, Cout, wdg_layer, Cin, g0, C0,
                      split_ch, g1, C1, B, H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
