@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a, con
     if (more) issue_loads(last_q ? 0 : q + 1);
 
     const float4* L = lds[buf];
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int gb = 0; gb < NG / 4; ++gb) {
 #pragma unroll
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a, con
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     buf ^= 1;
     if (!last_q) { ++q; continue; }
 

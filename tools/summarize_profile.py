@@ -44,3 +44,31 @@ for r in rows[:30]:
         "%.1f" % (2 * fr * 1024 / 1e6) if fr is not None else "", "%.1f" % (wr * 1024 / 1e6) if wr is not None else ""))
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
+
+# ---- category roll-up ----
+cats = collections.OrderedDict([
+    ("conv fwd (MFMA)", lambda k: "conv3x3_mfma_kernel" in k and "false" in k),
+    ("conv dgrad (MFMA)", lambda k: "conv3x3_mfma_kernel" in k and "true" in k),
+    ("dgrad border", lambda k: "dgrad_border" in k),
+    ("conv wgrad (MFMA)", lambda k: "conv3x3_wgrad" in k),
+    ("wgrad slab reduce", lambda k: "wgrad_reduce" in k),
+    ("BatchNorm backward", lambda k: "bn_bwd" in k),
+    ("BatchNorm finalize / eval", lambda k: "bn_finalize" in k or "bn_eval" in k or "nbt_" in k),
+    ("thin convs (in/out)", lambda k: "conv_in" in k or "conv_out" in k or "sum_partials" in k),
+    ("pool / upsample / residual", lambda k: "pool2" in k or "up2x" in k or "bnrelu_add" in k),
+    ("SIF loss", lambda k: "sif_loss" in k or "loss_finalize" in k or "blur" in k or "huber" in k or "sobel" in k),
+    ("Adam + weight pack", lambda k: "adam" in k or "pack_weights" in k),
+])
+agg = collections.OrderedDict((c, 0.0) for c in cats); agg["other (torch cat/copies)"] = 0.0
+for r in rows:
+    k = short(r["Name"]) + ("<" + r["Name"].split("<", 1)[1] if "<" in r["Name"] else "")
+    for c, f in cats.items():
+        if f(r["Name"]):
+            agg[c] += float(r["TotalDurationNs"]); break
+    else:
+        agg["other (torch cat/copies)"] += float(r["TotalDurationNs"])
+extra = ["", "| category | ms/step | % |", "|---|---|---|"]
+for c, v in agg.items():
+    extra.append("| %s | %.3f | %.1f |" % (c, v / 1e6 / steps, 100 * v / tot))
+open(f"profiles/{tag}_summary.md", "a").write("\n".join(extra) + "\n")
+print("\n".join(extra))
