@@ -276,3 +276,24 @@ def test_large_batch_properties(sifsr):
         grads.append(m.flat_grad().clone())
     assert torch.equal(grads[0], grads[1])
     assert torch.isfinite(grads[0]).all()
+
+
+def test_graph_captured_inference(sifsr, golden):
+    """BASELINE config 4: eval forward captured into a HIP graph; replays must equal the eager result
+    bit-for-bit and match the golden (reference) output."""
+    c = golden["cases"]["eval_w11_b21_B2"]
+    sd = O.synthetic_state(c["wseed"])
+    lst, lst_up, ndvi = O.synthetic_batch(c["bseed"], c["B"])
+    m = make_model(sifsr, sd).eval()
+    stats = {"mean_lst": MEAN, "std_lst": STD}
+    eager = sifsr.predict.predict_tiles(m, lst_up.cuda(), ndvi.cuda(), stats, batch=4)
+    gp = sifsr.predict.GraphedPredictor(m, batch=4, stats=stats)
+    for _ in range(3):
+        out = gp(lst_up.cuda(), ndvi.cuda())
+        assert torch.equal(out, eager)
+    check_digest(out.cpu(), c["y_denorm"], TOL)
+    # a different input through the same captured graph
+    lst2, lst_up2, ndvi2 = O.synthetic_batch(99, 3)
+    out2 = gp(lst_up2.cuda(), ndvi2.cuda())
+    ref2 = O.predict_tiles(sd, lst_up2, ndvi2, MEAN, STD)
+    assert rel_err(out2, ref2) < TOL

@@ -21,7 +21,7 @@ y = torch.empty(B, H, H, cout, device=dev)
 part = torch.empty(B * (H // 16) * (H // 16) * cout * 2, device=dev)
 dy = torch.randn(B, H, H, cout, device=dev)
 g = torch.empty(B, H, H, cin, device=dev)
-nblk = 2048 if 9 * cin * cout <= 4608 else 1024
+nblk = int(os.environ.get("NBLK", 2048 if 9 * cin * cout <= 4608 else 1024))
 scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_scratch_floats", cin, cout, nblk), device=dev)
 dw = torch.empty_like(w)
 def run():
