@@ -331,3 +331,30 @@ def test_adam_flat(L):
     torch.cuda.synchronize()
     assert rel_err(p.cpu(), sd["p"]) < 1e-6
     assert rel_err(p.cpu() - p0, sd["p"] - p0) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 256, 256, 2), (16, 16, 128, 128, 8), (32, 16, 256, 256, 1),
+                                   (64, 32, 128, 128, 4), (64, 64, 32, 32, 16), (128, 64, 64, 64, 4)])
+def test_conv3x3_full_size_grids(L, shape):
+    """Layer-sized problems: enough tiles that the persistent kernels run two workgroups per CU and several
+    tiles per workgroup (the small cases above never do) -- forward and dgrad, repeated to expose races."""
+    cin, cout, H, W, B = shape
+    rs = np.random.RandomState(sum(shape))
+    x = rnd(rs, B, cin, H, W)
+    w = rnd(rs, cout, cin, 3, 3, scale=(2.0 / (9 * cin)) ** 0.5)
+    a = x.clone().requires_grad_(True)
+    y_ref = conv_rep(a, w)
+    dy = rnd(rs, B, cout, H, W)
+    (ga_ref,) = torch.autograd.grad((y_ref * dy).sum(), [a])
+    wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(2 * 9 * cin * cout, device="cuda")
+    dw_ = dev(w)
+    L.call("sifsr_pack_conv_weights", dw_, cin, cout, wf, wd, S())
+    dx, ddy = dev(nhwc(x)), dev(nhwc(dy))
+    for _ in range(3):
+        y = torch.full((B, H, W, cout), float("nan"), device="cuda")
+        g = torch.full((B, H, W, cin), float("nan"), device="cuda")
+        L.call("sifsr_conv3x3_fwd", dx, cin, None, None, None, 0, None, None, wf, y, cout, None, B, H, W, S())
+        L.call("sifsr_conv3x3_dgrad", ddy, cout, wd, dw_, cin, g, cin, None, 0, None, B, H, W, S())
+        torch.cuda.synchronize()
+        assert rel_err(nchw(y.cpu()), y_ref) < TOL
+        assert rel_err(nchw(g.cpu()), ga_ref) < TOL
