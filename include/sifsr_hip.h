@@ -82,6 +82,20 @@ SIFSR_API int sifsr_conv_out_fwd(const float* y, const float* scale, const float
 SIFSR_API int sifsr_conv_out_dgrad(const float* dsr, const float* w, float* g, int B, int H, int W, void* stream);
 SIFSR_API int sifsr_conv_out_wgrad(const float* y, const float* scale, const float* shift, const float* dsr, float* scratch,
                                    int nblk, float* dwb, int B, int H, int W, void* stream);
+/* Fused tail of the backward pass (model.py:605 <- :139-141): outlay dW|db (145 floats -> dwb), and the BatchNorm+ReLU
+ * backward of the layer feeding outlay with the outlay input gradient recomputed from dsr instead of stored:
+ * y = raw conv output (B,H,W,16) -> dgamma, dbeta, dy.  scratch: >= 64 + nblk*(145+32) floats; coef: 48 float64. */
+SIFSR_API int sifsr_conv_out_bn_relu_bwd(const float* y, const float* scale, const float* shift, const float* mean,
+                                         const float* invstd, const float* dsr, const float* w, float* scratch, int nblk,
+                                         float* dwb, float* dgamma, float* dbeta, double* coef, float* dy, int B, int H,
+                                         int W, void* stream);
+/* Fused head of the backward pass (model.py:596 / :135-137): BatchNorm+ReLU backward of inbloc.bloc.0-2 + the input
+ * conv's weight gradient; dy = dL/dy is formed inside the wgrad staging and never stored (the model input needs no
+ * gradient).  g = dL/d relu(bn(y)).  scratch: >= nblk*288 floats, nblk <= 1024; coef: 48 float64. */
+SIFSR_API int sifsr_conv_in_bn_relu_bwd(const float* x, const float* g, const float* y, const float* scale,
+                                        const float* shift, const float* mean, const float* invstd, float* scratch,
+                                        int nblk, float* dw, float* dgamma, float* dbeta, double* coef, int B, int H, int W,
+                                        void* stream);
 
 /* ---- BatchNorm2d (model.py:136,139,508; eps 1e-5, momentum 0.1) ------------------------------ */
 SIFSR_API int sifsr_bn_finalize(const float* stat_partials, int nblk, int C, double count, const float* gamma,

@@ -128,6 +128,35 @@ int sifsr_conv_out_wgrad(const float* y, const float* scale, const float* shift,
   return launch_conv_out_wgrad(y, scale, shift, dsr, scratch, nblk, dwb, dwb + 144, B, H, W, S(stream));
 }
 
+int sifsr_conv_out_bn_relu_bwd(const float* y, const float* scale, const float* shift, const float* mean,
+                               const float* invstd, const float* dsr, const float* w, float* scratch, int nblk,
+                               float* dwb, float* dgamma, float* dbeta, double* coef, float* dy, int B, int H, int W,
+                               void* stream) {
+  if (!y || !scale || !shift || !mean || !invstd || !dsr || !w || !scratch || !dwb || !dgamma || !dbeta || !coef || !dy)
+    return SIFSR_ERR_ARG;
+  float* bnpart = scratch + (((size_t)nblk * 145 + 63) & ~(size_t)63);
+  int rc = launch_tail_bwd_reduce(y, scale, shift, mean, invstd, dsr, w, scratch, bnpart, nblk, B, H, W, S(stream));
+  if (rc) return rc;
+  rc = launch_sum_partials(scratch, nblk, 145, dwb, S(stream));
+  if (rc) return rc;
+  rc = launch_bn_bwd_finalize(bnpart, nblk, 16, (double)B * H * W, scale, mean, invstd, dgamma, dbeta, coef, S(stream));
+  if (rc) return rc;
+  return launch_tail_bwd_apply(y, scale, shift, coef, dsr, w, dy, B, H, W, S(stream));
+}
+int sifsr_conv_in_bn_relu_bwd(const float* x, const float* g, const float* y, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, float* scratch, int nblk, float* dw, float* dgamma,
+                              float* dbeta, double* coef, int B, int H, int W, void* stream) {
+  if (!x || !g || !y || !scale || !shift || !mean || !invstd || !scratch || !dw || !dgamma || !dbeta || !coef)
+    return SIFSR_ERR_ARG;
+  if (nblk < 1 || nblk > 1024) return SIFSR_ERR_ARG;
+  const size_t npix = (size_t)B * H * W;
+  int rc = launch_bn_bwd_reduce(g, y, scale, shift, mean, invstd, 16, npix, scratch, nblk, S(stream));
+  if (rc) return rc;
+  rc = launch_bn_bwd_finalize(scratch, nblk, 16, (double)npix, scale, mean, invstd, dgamma, dbeta, coef, S(stream));
+  if (rc) return rc;
+  return launch_conv_in_wgrad_fused(x, g, y, scale, shift, coef, scratch, nblk, dw, B, H, W, S(stream));
+}
+
 int sifsr_bn_finalize(const float* stat_partials, int nblk, int C, double count, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                       float* scale, float* shift, void* stream) {

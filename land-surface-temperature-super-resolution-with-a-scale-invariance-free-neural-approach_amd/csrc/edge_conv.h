@@ -11,6 +11,14 @@ int launch_conv_out_fwd(const float* y, const float* scale, const float* shift, 
 int launch_conv_out_dgrad(const float* dsr, const float* w, float* g, int B, int H, int W, hipStream_t s);
 int launch_conv_out_wgrad(const float* y, const float* scale, const float* shift, const float* dsr, float* partials,
                           int nblk, float* dw, float* db, int B, int H, int W, hipStream_t s);
+int launch_conv_in_wgrad_fused(const float* x, const float* g, const float* y, const float* scale, const float* shift,
+                               const double* coef, float* partials, int nblk, float* dw, int B, int H, int W, hipStream_t s);
+// ---- fused_edges.hip ---- (outlay backward + BatchNorm/ReLU backward of its producer)
+int launch_tail_bwd_reduce(const float* y, const float* scale, const float* shift, const float* mean, const float* invstd,
+                           const float* dsr, const float* w, float* wpart, float* bnpart, int nblk, int B, int H, int W,
+                           hipStream_t s);
+int launch_tail_bwd_apply(const float* y, const float* scale, const float* shift, const double* coef, const float* dsr,
+                          const float* w, float* dy, int B, int H, int W, hipStream_t s);
 int launch_sum_partials(const float* partials, int nblk, int n, float* out, hipStream_t s);
 
 // ---- bn.hip ----

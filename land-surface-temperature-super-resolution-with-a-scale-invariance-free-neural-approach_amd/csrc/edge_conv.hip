@@ -13,6 +13,7 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
                                                           float* __restrict__ y, float* __restrict__ partials,
                                                           int H, int W) {
   __shared__ float tile[2][18 * 18];
+  __shared__ float ost[256 * 17];
   __shared__ float red[4][16][2];
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16, b = blockIdx.z;
@@ -42,13 +43,20 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
   for (int c4 = 0; c4 < 4; ++c4) st4(yp + 4 * c4, make_float4(o[4 * c4], o[4 * c4 + 1], o[4 * c4 + 2], o[4 * c4 + 3]));
 
   if (partials != nullptr) {
+    // transpose through LDS: thread (co = tid & 15, seg = tid >> 4) sums 16 pixels of one channel, then a
+    // 2-step shuffle over the 4 segments inside a wave instead of a 64-lane butterfly per channel
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int co = 0; co < 16; ++co) {
-      float u = o[co], v = o[co] * o[co];
+    for (int co = 0; co < 16; ++co) ost[tid * 17 + co] = o[co];
+    __syncthreads();
+    {
+      const int co = tid & 15, seg = tid >> 4;
+      float u = 0.f, v = 0.f;
 #pragma unroll
-      for (int m = 1; m < 64; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
-      if (lane == 0) { red[wave][co][0] = u; red[wave][co][1] = v; }
+      for (int i = 0; i < 16; ++i) { const float t = ost[(seg * 16 + i) * 17 + co]; u += t; v = fmaf(t, t, v); }
+      u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
+      u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
+      if (lane < 16) { red[wave][co][0] = u; red[wave][co][1] = v; }
     }
     __syncthreads();
     if (tid < 32) {
@@ -65,7 +73,15 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
 //   A lane (i = co, k = pixel)  <- dy tile [256 px][16]        (conflict-free: pixel stride 16 floats)
 //   B lane (j = n,  k = pixel)  <- x halo planes at a per-lane constant (ci, tap) offset
 // Persistent workgroups; each wave takes every 4th k-step; partial [blk][288] summed by sum_partials_kernel.
+// FUSED: dy is not read but computed while staging, dy = scale*g*[z>0] + k1*y + k0 (the BatchNorm+ReLU backward
+// of inbloc.bloc.1/2; `dy` then holds g) -- the first layer has no input gradient, so this wgrad is dy's only
+// consumer and dy never goes to HBM.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ yraw,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const double* __restrict__ coef,
                                                             float* __restrict__ partials, int B, int H, int W) {
   __shared__ float tile[2 * 324 + 8];
   __shared__ float dyt[256 * 16];
@@ -80,6 +96,14 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restr
     offn[nt] = n < 18 ? (n / 9) * 324 + ((n % 9) / 3) * 18 + (n % 9) % 3 : 0;   // n >= 18: columns never stored
   }
   f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  float4 sc4, sh4;
+  double sd[4], k1[4], k0[4];
+  if (FUSED) {
+    const int q4 = tid & 3;   // the staging loop below gives every thread a fixed channel quad
+    sc4 = ld4(scale + 4 * q4); sh4 = ld4(shift + 4 * q4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sd[j] = coef[4 * q4 + j]; k1[j] = coef[16 + 4 * q4 + j]; k0[j] = coef[32 + 4 * q4 + j]; }
+  }
   for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
     const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, b = tl / (tiles_x * tiles_y);
     const int x0 = tx * 16, y0 = ty * 16;
@@ -92,8 +116,16 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restr
     }
     for (int e = tid; e < 256 * 4; e += 256) {
       const int p = e >> 2, c4 = e & 3;
-      *reinterpret_cast<float4*>(&dyt[p * 16 + 4 * c4]) =
-          ld4(dy + ((size_t)(b * H + y0 + (p >> 4)) * W + x0 + (p & 15)) * 16 + 4 * c4);
+      const size_t off = ((size_t)(b * H + y0 + (p >> 4)) * W + x0 + (p & 15)) * 16 + 4 * c4;
+      float4 v = ld4(dy + off);
+      if (FUSED) {
+        const float4 yv = ld4(yraw + off);
+        v.x = (float)fma(sd[0], (double)(fmaf(yv.x, sc4.x, sh4.x) > 0.f ? v.x : 0.f), fma(k1[0], (double)yv.x, k0[0]));
+        v.y = (float)fma(sd[1], (double)(fmaf(yv.y, sc4.y, sh4.y) > 0.f ? v.y : 0.f), fma(k1[1], (double)yv.y, k0[1]));
+        v.z = (float)fma(sd[2], (double)(fmaf(yv.z, sc4.z, sh4.z) > 0.f ? v.z : 0.f), fma(k1[2], (double)yv.z, k0[2]));
+        v.w = (float)fma(sd[3], (double)(fmaf(yv.w, sc4.w, sh4.w) > 0.f ? v.w : 0.f), fma(k1[3], (double)yv.w, k0[3]));
+      }
+      *reinterpret_cast<float4*>(&dyt[p * 16 + 4 * c4]) = v;
     }
     __syncthreads();
 #pragma unroll 4
@@ -285,7 +317,18 @@ int launch_conv_in_fwd(const float* x, const float* w, float* y, float* partials
 int launch_conv_in_wgrad(const float* x, const float* dy, float* partials, int nblk, float* dw, int B, int H, int W,
                          hipStream_t s) {
   if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
-  hipLaunchKernelGGL(conv_in_wgrad_kernel, dim3(nblk), dim3(256), 0, s, x, dy, partials, B, H, W);
+  hipLaunchKernelGGL((conv_in_wgrad_kernel<false>), dim3(nblk), dim3(256), 0, s, x, dy, nullptr, nullptr, nullptr, nullptr,
+                     partials, B, H, W);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(9), dim3(256), 0, s, partials, nblk, 288, dw);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_conv_in_wgrad_fused(const float* x, const float* g, const float* y, const float* scale, const float* shift,
+                               const double* coef, float* partials, int nblk, float* dw, int B, int H, int W,
+                               hipStream_t s) {
+  if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
+  hipLaunchKernelGGL((conv_in_wgrad_kernel<true>), dim3(nblk), dim3(256), 0, s, x, g, y, scale, shift, coef, partials, B, H, W);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(9), dim3(256), 0, s, partials, nblk, 288, dw);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;

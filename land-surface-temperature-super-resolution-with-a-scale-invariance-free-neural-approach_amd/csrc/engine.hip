@@ -318,13 +318,22 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   const NetTable& nt = c.nt;
   const WsLayout& w = c.lay;
 
-  // outlay
+  // outlay backward fused with the BatchNorm+ReLU backward of ub3.convbloc.bloc.3 (fused_edges.hip): the outlay
+  // input gradient is recomputed from dsr in both passes instead of being stored; dy(L_U3B) -> g[L_U3B]
   {
+    const LayerInfo& L = nt.L[L_U3B];
     int nblk = B * (H / 16) * (W / 16);
     if (nblk > 1024) nblk = 1024;
-    SIFSR_TRY(launch_conv_out_wgrad(c.f(w.y[L_U3B]), c.scale(L_U3B), c.shift(L_U3B), dsr, c.f(w.slabs), nblk,
-                                    grads + nt.out_w_off, grads + nt.out_b_off, B, H, W, s));
-    SIFSR_TRY(launch_conv_out_dgrad(dsr, params + nt.out_w_off, c.f(w.g[L_U3B]), B, H, W, s));
+    const float* y = c.f(w.y[L_U3B]);
+    SIFSR_TRY(launch_tail_bwd_reduce(y, c.scale(L_U3B), c.shift(L_U3B), c.f(w.mean) + L.ch_off, c.f(w.invstd) + L.ch_off, dsr,
+                                     params + nt.out_w_off, c.f(w.slabs), c.f(w.partials), nblk, B, H, W, s));
+    if (grads + nt.out_b_off != grads + nt.out_w_off + 144) return SIFSR_ERR_ARG;
+    SIFSR_TRY(launch_sum_partials(c.f(w.slabs), nblk, 145, grads + nt.out_w_off, s));
+    SIFSR_TRY(launch_bn_bwd_finalize(c.f(w.partials), nblk, 16, (double)w.npix[0], c.scale(L_U3B), c.f(w.mean) + L.ch_off,
+                                     c.f(w.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
+                                     reinterpret_cast<double*>(c.f(w.coef)), s));
+    SIFSR_TRY(launch_tail_bwd_apply(y, c.scale(L_U3B), c.shift(L_U3B), reinterpret_cast<const double*>(c.f(w.coef)), dsr,
+                                    params + nt.out_w_off, c.f(w.g[L_U3B]), B, H, W, s));
   }
 
   // decoder, last to first
@@ -334,8 +343,8 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   for (int k = 2; k >= 0; --k) {
     const int lv = 2 - k;
     const int la = dec_a[k], lb = dec_b[k], ls = dec_skip[k], ll = dec_low[k];
-    // second conv of the DoubleConvolution
-    SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), c.f(w.g[lb]), grads));
+    // second conv of the DoubleConvolution (k == 2: dy already produced by the fused tail above)
+    if (k != 2) SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), c.f(w.g[lb]), grads));
     SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads));
     SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), nt.L[la].cout, nt.L[lb].cin, nullptr, 0, nullptr));
     // first conv: input = cat([U_k, relu(bn(y_skip))])
@@ -370,11 +379,24 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   SIFSR_TRY(bn_unit_bwd(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN3]), grads));
   SIFSR_TRY(conv_unit_wgrad(c, L_IN3, src_act(c, L_IN0), src_none(), c.f(w.g[L_IN3]), grads));
   SIFSR_TRY(conv_unit_dgrad(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), 16, 16, nullptr, 0, nullptr));
-  SIFSR_TRY(bn_unit_bwd(c, L_IN0, c.f(w.g[L_IN0]), c.f(w.g[L_IN0]), grads));
+  // first layer: no input gradient, so dy(L_IN0) is consumed by the weight gradient alone and is formed on the
+  // fly from (g, y) in its staging loop -- BatchNorm backward is reduce + finalize only
   {
+    const LayerInfo& L = nt.L[L_IN0];
+    const size_t npix = w.npix[0];
+    const size_t nb = npix / 256;
+    const int nblk_r = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+    const float* y = c.f(w.y[L_IN0]);
+    SIFSR_TRY(launch_bn_bwd_reduce(c.f(w.g[L_IN0]), y, c.scale(L_IN0), c.shift(L_IN0), c.f(w.mean) + L.ch_off,
+                                   c.f(w.invstd) + L.ch_off, 16, npix, c.f(w.partials), nblk_r, s));
+    SIFSR_TRY(launch_bn_bwd_finalize(c.f(w.partials), nblk_r, 16, (double)npix, c.scale(L_IN0), c.f(w.mean) + L.ch_off,
+                                     c.f(w.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
+                                     reinterpret_cast<double*>(c.f(w.coef)), s));
     int nblk = B * (H / 16) * (W / 16);
     if (nblk > 1024) nblk = 1024;
-    SIFSR_TRY(launch_conv_in_wgrad(x, c.f(w.g[L_IN0]), c.f(w.slabs), nblk, grads + nt.L[L_IN0].w_off, B, H, W, s));
+    SIFSR_TRY(launch_conv_in_wgrad_fused(x, c.f(w.g[L_IN0]), y, c.scale(L_IN0), c.shift(L_IN0),
+                                         reinterpret_cast<const double*>(c.f(w.coef)), c.f(w.slabs), nblk,
+                                         grads + L.w_off, B, H, W, s));
   }
   return SIFSR_OK;
 }

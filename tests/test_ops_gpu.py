@@ -358,3 +358,74 @@ def test_conv3x3_full_size_grids(L, shape):
         torch.cuda.synchronize()
         assert rel_err(nchw(y.cpu()), y_ref) < TOL
         assert rel_err(nchw(g.cpu()), ga_ref) < TOL
+
+
+def _bn_setup(L, rs, y, gamma, beta):
+    """batch statistics -> (mean, invstd, scale, shift) on the device through sifsr_bn_finalize"""
+    B, C, H, W = y.shape
+    t = y.unfold(2, 16, 16).unfold(3, 16, 16)
+    p1 = t.sum((-1, -2)).permute(0, 2, 3, 1).reshape(-1, C)
+    p2 = (t * t).sum((-1, -2)).permute(0, 2, 3, 1).reshape(-1, C)
+    part = dev(torch.stack([p1, p2], -1))
+    mean, invstd, scale, shift = (torch.empty(C, device="cuda") for _ in range(4))
+    L.call("sifsr_bn_finalize", part, part.shape[0], C, float(B * H * W), dev(gamma), dev(beta), None, None, 0.1, 1e-5,
+           mean, invstd, scale, shift, S())
+    return mean, invstd, scale, shift
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 16, 16), (3, 64, 32)])
+def test_fused_tail_backward(L, shape):
+    """sifsr_conv_out_bn_relu_bwd == autograd of conv_out(relu(bn(y))) w.r.t. (y, gamma, beta, w_out, b_out):
+    the image borders (replicate-padding adjoint) are inside every case, (1,16,16) is one tile with all four."""
+    B, H, W = shape
+    rs = np.random.RandomState(11 + H)
+    y = (rnd(rs, B, 16, H, W) * 1.3 + 0.2).requires_grad_(True)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, 16).astype(np.float32)).requires_grad_(True)
+    beta = rnd(rs, 16, scale=0.2).requires_grad_(True)
+    w = rnd(rs, 1, 16, 3, 3, scale=0.2).requires_grad_(True)
+    b = rnd(rs, 1).requires_grad_(True)
+    a = F.relu(F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5))
+    out = conv_rep(a, w, b)
+    dsr = rnd(rs, B, 1, H, W)
+    gy, gg, gb, gw, gbias = torch.autograd.grad((out * dsr).sum(), [y, gamma, beta, w, b])
+
+    mean, invstd, scale, shift = _bn_setup(L, rs, y.detach(), gamma.detach(), beta.detach())
+    for nblk in (3, B * (H // 16) * (W // 16)):
+        scratch = torch.empty(64 + nblk * (145 + 32), device="cuda")
+        dwb = torch.empty(145, device="cuda")
+        dgam, dbet = (torch.empty(16, device="cuda") for _ in range(2))
+        coef = torch.empty(48, dtype=torch.float64, device="cuda")
+        dy = torch.full((B, H, W, 16), float("nan"), device="cuda")
+        L.call("sifsr_conv_out_bn_relu_bwd", dev(nhwc(y.detach())), scale, shift, mean, invstd, dev(dsr), dev(w.detach()),
+               scratch, nblk, dwb, dgam, dbet, coef, dy, B, H, W, S())
+        torch.cuda.synchronize()
+        assert rel_err(nchw(dy.cpu()), gy) < TOL
+        assert rel_err(dgam.cpu(), gg) < TOL and rel_err(dbet.cpu(), gb) < TOL
+        assert rel_err(dwb.cpu()[:144].view(1, 16, 3, 3), gw) < TOL
+        assert rel_err(dwb.cpu()[144:], gbias) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 16, 16)])
+def test_fused_head_backward(L, shape):
+    """sifsr_conv_in_bn_relu_bwd == autograd of relu(bn(conv_in(x))) w.r.t. (w_in, gamma, beta)"""
+    B, H, W = shape
+    rs = np.random.RandomState(17 + H)
+    x = rnd(rs, B, 2, H, W)
+    w = rnd(rs, 16, 2, 3, 3, scale=0.3).requires_grad_(True)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, 16).astype(np.float32)).requires_grad_(True)
+    beta = rnd(rs, 16, scale=0.2).requires_grad_(True)
+    y = conv_rep(x, w)
+    a = F.relu(F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5))
+    g = rnd(rs, B, 16, H, W)
+    gw, gg, gb = torch.autograd.grad((a * g).sum(), [w, gamma, beta])
+    mean, invstd, scale, shift = _bn_setup(L, rs, y.detach(), gamma.detach(), beta.detach())
+    nblk = 3
+    scratch = torch.empty(nblk * 288, device="cuda")
+    dw = torch.empty(16, 2, 3, 3, device="cuda")
+    dgam, dbet = (torch.empty(16, device="cuda") for _ in range(2))
+    coef = torch.empty(48, dtype=torch.float64, device="cuda")
+    L.call("sifsr_conv_in_bn_relu_bwd", dev(x), dev(nhwc(g)), dev(nhwc(y.detach())), scale, shift, mean, invstd, scratch,
+           nblk, dw, dgam, dbet, coef, B, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), gw) < TOL
+    assert rel_err(dgam.cpu(), gg) < TOL and rel_err(dbet.cpu(), gb) < TOL
