@@ -210,21 +210,27 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
 
 // dW[co][ci][t] = sum over workgroups of slab[blk][chunk][nbo][nbi][t][lane][r]
 //   co = 16 nbo + 4 (lane>>4) + r,  ci = 16 (chunk*NBI + nbi) + (lane & 15)
-// One thread per slab element j (so every pass over the slabs is a coalesced stream), 8 slab groups
-// per element reduced through LDS in a fixed order, scattered once to the OIHW gradient.
+// EL consecutive slab elements x (256 / EL) slab groups per workgroup, tree-reduced through LDS in a fixed order
+// and scattered once to the OIHW gradient.  Small layers use a small EL so that the (latency-bound) walk over
+// the slabs is spread over >= ~500 workgroups.
+template <int EL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nblk, int cin, int cout,
                                                            int nbi_chunk, float* __restrict__ dw) {
-  __shared__ double part[8][32];
+  constexpr int GR = 256 / EL;
+  __shared__ double part[GR][EL];
   const int n = 9 * cin * cout;
-  const int jl = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + jl;
+  const int jl = threadIdx.x % EL, grp = threadIdx.x / EL;
+  const int j = blockIdx.x * EL + jl;
   double s = 0.0;
   if (j < n)
-    for (int k = grp; k < nblk; k += 8) s += (double)slabs[(size_t)k * n + j];
+    for (int k = grp; k < nblk; k += GR) s += (double)slabs[(size_t)k * n + j];
   part[grp][jl] = s;
   __syncthreads();
+  for (int st = GR / 2; st > 0; st >>= 1) {
+    if (grp < st) part[grp][jl] += part[grp + st][jl];
+    __syncthreads();
+  }
   if (grp == 0 && j < n) {
-    for (int g = 1; g < 8; ++g) s += part[g][jl];
     const int r = j & 3, lane = (j >> 2) & 63;
     const int rest = j >> 8;
     const int t = rest % 9, r2 = rest / 9;
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int nbi = r2 % nbi_chunk, r3 = r2 / nbi_chunk;
     const int nbo = r3 % NBO, chunk = r3 / NBO;
     const int co = 16 * nbo + 4 * (lane >> 4) + r, ci = 16 * (chunk * nbi_chunk + nbi) + (lane & 15);
-    dw[(co * cin + ci) * 9 + t] = (float)s;
+    dw[(co * cin + ci) * 9 + t] = (float)part[0][jl];
   }
 }
 
@@ -279,8 +285,14 @@ int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStr
 
 int launch_wgrad_reduce(const float* slabs, int nblk, int cin, int cout, int nbi_chunk, float* dw_oihw, hipStream_t s) {
   const int n = 9 * cin * cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, slabs, nblk, cin, cout,
-                     nbi_chunk, dw_oihw);
+  if (n <= 2304)
+    hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3((n + 3) / 4), dim3(256), 0, s, slabs, nblk, cin, cout, nbi_chunk, dw_oihw);
+  else if (n <= 4608)
+    hipLaunchKernelGGL((wgrad_reduce_kernel<8>), dim3((n + 7) / 8), dim3(256), 0, s, slabs, nblk, cin, cout, nbi_chunk, dw_oihw);
+  else if (n <= 9216)
+    hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3((n + 15) / 16), dim3(256), 0, s, slabs, nblk, cin, cout, nbi_chunk, dw_oihw);
+  else
+    hipLaunchKernelGGL((wgrad_reduce_kernel<32>), dim3((n + 31) / 32), dim3(256), 0, s, slabs, nblk, cin, cout, nbi_chunk, dw_oihw);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

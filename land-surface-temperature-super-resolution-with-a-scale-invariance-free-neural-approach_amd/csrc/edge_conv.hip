@@ -288,21 +288,22 @@ __global__ __launch_bounds__(256) void conv_out_wgrad_kernel(const float* __rest
   }
 }
 
-// out[e] = sum_k partials[k][e] in float64, fixed order (deterministic): 32 outputs x 8 row groups per block
+// out[e] = sum_k partials[k][e] in float64, fixed order (deterministic): 4 outputs x 64 row lanes per block
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partials, int nblk, int n,
                                                            float* __restrict__ out) {
-  __shared__ double part[8][32];
-  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + el;
+  __shared__ double part[64][4];
+  const int el = threadIdx.x & 3, grp = threadIdx.x >> 2;
+  const int e = blockIdx.x * 4 + el;
   double s = 0.0;
   if (e < n)
-    for (int k = grp; k < nblk; k += 8) s += (double)partials[(size_t)k * n + e];
+    for (int k = grp; k < nblk; k += 64) s += (double)partials[(size_t)k * n + e];
   part[grp][el] = s;
   __syncthreads();
-  if (grp == 0 && e < n) {
-    for (int g = 1; g < 8; ++g) s += part[g][el];
-    out[e] = (float)s;
+  for (int st = 32; st > 0; st >>= 1) {
+    if (grp < st) part[grp][el] += part[grp + st][el];
+    __syncthreads();
   }
+  if (grp == 0 && e < n) out[e] = (float)part[0][el];
 }
 
 }  // namespace
@@ -319,7 +320,7 @@ int launch_conv_in_wgrad(const float* x, const float* dy, float* partials, int n
   if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
   hipLaunchKernelGGL((conv_in_wgrad_kernel<false>), dim3(nblk), dim3(256), 0, s, x, dy, nullptr, nullptr, nullptr, nullptr,
                      partials, B, H, W);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(9), dim3(256), 0, s, partials, nblk, 288, dw);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(72), dim3(256), 0, s, partials, nblk, 288, dw);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
@@ -329,7 +330,7 @@ int launch_conv_in_wgrad_fused(const float* x, const float* g, const float* y, c
                                hipStream_t s) {
   if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
   hipLaunchKernelGGL((conv_in_wgrad_kernel<true>), dim3(nblk), dim3(256), 0, s, x, g, y, scale, shift, coef, partials, B, H, W);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(9), dim3(256), 0, s, partials, nblk, 288, dw);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(72), dim3(256), 0, s, partials, nblk, 288, dw);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
@@ -357,13 +358,13 @@ int launch_conv_out_wgrad(const float* y, const float* scale, const float* shift
   hipLaunchKernelGGL(conv_out_wgrad_kernel, dim3(nblk), dim3(256), 0, s, y, scale, shift, dsr, partials, B, H, W);
   // dw (144 floats) and db (1 float) are adjacent in the flat gradient buffer (outlay.weight, outlay.bias)
   if (db != dw + 144) return SIFSR_ERR_ARG;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(5), dim3(256), 0, s, partials, nblk, 145, dw);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(37), dim3(256), 0, s, partials, nblk, 145, dw);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
 
 int launch_sum_partials(const float* partials, int nblk, int n, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(sum_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, s, partials, nblk, n, out);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((n + 3) / 4), dim3(256), 0, s, partials, nblk, n, out);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
