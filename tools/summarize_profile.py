@@ -52,6 +52,7 @@ cats = collections.OrderedDict([
     ("dgrad border", lambda k: "dgrad_border" in k),
     ("conv wgrad (MFMA)", lambda k: "conv3x3_wgrad" in k),
     ("wgrad slab reduce", lambda k: "wgrad_reduce" in k),
+    ("fused tail (outlay bwd + BN bwd)", lambda k: "tail_bwd" in k),
     ("BatchNorm backward", lambda k: "bn_bwd" in k),
     ("BatchNorm finalize / eval", lambda k: "bn_finalize" in k or "bn_eval" in k or "nbt_" in k),
     ("thin convs (in/out)", lambda k: "conv_in" in k or "conv_out" in k or "sum_partials" in k),
