@@ -49,12 +49,16 @@ const NetTable& sifsr_net() {
 // ---------------------------------------------------------------------------------------------
 static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }   // in floats (256 B)
 
-static int wgrad_blocks(int chunks, int ntiles) {
-  // persistent, software-pipelined workgroups: about two per CU are resident (LDS / VGPR), so launch about
-  // that many (x the Cin chunks in blockIdx.y); fewer slabs also make the slab reduction cheaper.
-  int n = 512 / chunks;
-  if (n < 128) n = 128;
-  return ntiles < n ? ntiles : n;
+static int wgrad_blocks(int cin, int cout, int chunks, int ntiles) {
+  // persistent, software-pipelined workgroups: two per CU are resident (four for the 16->16 variant: 20 KB LDS,
+  // 66 VGPRs), so launch that many in total (x-dim = total / Cin chunks in blockIdx.y), but keep >= 4 tiles per
+  // workgroup so that the slab write + slab reduction stay small next to the MFMA work (measured per layer).
+  const int total = (cin == 16 && cout == 16) ? 1024 : 512;
+  int n = total / chunks;
+  if (n < 64) n = 64;
+  const int cap = ntiles / 4 > 0 ? ntiles / 4 : 1;
+  if (n > cap) n = cap;
+  return n;
 }
 
 int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
@@ -96,7 +100,7 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
     size_t maxslab = 1024 * 288;   // edge-layer partials
     for (int l = 1; l < SIFSR_NUM_BN_LAYERS; ++l) {
       const int ntiles = (int)(N[nt.L[l].level] / 128);
-      const size_t n = (size_t)wgrad_blocks(1, ntiles) * 9 * nt.L[l].cin * nt.L[l].cout;   // upper bound over chunkings
+      const size_t n = (size_t)wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles) * 9 * nt.L[l].cin * nt.L[l].cout;   // upper bound over chunkings
       maxslab = n > maxslab ? n : maxslab;
     }
     w.slabs = take(maxslab);
@@ -207,7 +211,7 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
   a.NQ = L.cin / 16;
   a.ntiles = c.B * (a.H / 8) * (a.W / 16);
   const int nbi = wgrad_nbi_chunk(a, L.cin);
-  const int nblk = wgrad_blocks(L.cin / (16 * nbi), a.ntiles);
+  const int nblk = wgrad_blocks(L.cin, L.cout, L.cin / (16 * nbi), a.ntiles);
   {
     ProfScope ps(l, 3, c.s);
     SIFSR_TRY(launch_conv3x3_wgrad(a, L.cin, L.cout, nblk, c.s));
