@@ -101,10 +101,12 @@ SIFSR_API int sifsr_conv_in_bn_relu_bwd(const float* x, const float* g, const fl
 SIFSR_API int sifsr_bn_finalize(const float* stat_partials, int nblk, int C, double count, const float* gamma,
                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                 float* mean, float* invstd, float* scale, float* shift, void* stream);
-/* g = dL/d relu(bn(y)) -> dgamma, dbeta, dy = dL/dy; partials: >= nblk*C*2 floats; coef: 3*C float64 scratch */
+/* g = dL/d relu(bn(y)) -> dgamma, dbeta, dy = dL/dy; partials: >= nblk*C*2 floats; coef: 3*C float64 scratch.
+ * gpool != NULL: the activation also feeds AvgPool2d(2,2) (model.py:504); gpool = gradient of the pooled tensor
+ * (B,H/2,W/2,C) and g_eff = g + 0.25*gpool[y/2][x/2] is formed on the fly (npix = B*H*W); else H, W are ignored. */
 SIFSR_API int sifsr_bn_relu_bwd(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
                                 const float* invstd, int C, size_t npix, float* partials, int nblk, float* dgamma,
-                                float* dbeta, double* coef, float* dy, void* stream);
+                                float* dbeta, double* coef, float* dy, const float* gpool, int H, int W, void* stream);
 
 /* ---- resampling (NHWC; scale == NULL: input used as stored) ---------------------------------- */
 SIFSR_API int sifsr_bnrelu_pool2(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W, int C, void* stream); /* AvgPool2d(2,2), model.py:504 */

@@ -59,6 +59,20 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ params, const fl
   shift[tb.ch_off[l] + c] = fmaf(-rm, sc, params[tb.beta_off[l] + c]);
 }
 
+// Optional second gradient source: the AvgPool2d(2,2) adjoint of a half-resolution gradient gp, added on the fly,
+//   g_eff[y][x] = g[y][x] + 0.25 * gp[y/2][x/2]
+// (the skip layers inbloc.bloc.3 / db1,2.lastconv feed both the decoder skip and the next pooling stage; this
+// replaces a separate read-modify-write pass over g).  W2 = W/2 etc. describe the full-resolution image.
+struct PoolAdj { const float* gp; int H, W; };
+template <int C>
+__device__ __forceinline__ float4 pool_adj4(const PoolAdj pa, size_t p, int c4) {
+  const unsigned W = (unsigned)pa.W, H = (unsigned)pa.H;
+  const unsigned x = (unsigned)(p % W), r = (unsigned)(p / W);
+  const unsigned yy = r % H, b = r / H;
+  const float4 v = ld4(pa.gp + (((size_t)b * (H / 2) + yy / 2) * (W / 2) + x / 2) * C + 4 * c4);
+  return make_float4(0.25f * v.x, 0.25f * v.y, 0.25f * v.z, 0.25f * v.w);
+}
+
 // per-workgroup partial (sum dz, sum dz*xhat) per channel
 template <int C>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y,
@@ -66,7 +80,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, size_t npix,
-                                                            float* __restrict__ partials) {
+                                                            float* __restrict__ partials, const PoolAdj pa) {
   constexpr int Q = C / 4;          // channel quads
   constexpr int PP = 256 / Q;       // pixels per pass per workgroup
   __shared__ double red[256][8];   // float64 accumulation: dy = scale*(dz - mean(dz) - ...) cancels heavily
@@ -74,7 +88,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const float4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4), mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4);
   double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
   for (size_t p = (size_t)blockIdx.x * PP + pl; p < npix; p += (size_t)gridDim.x * PP) {
-    const float4 yv = ld4(y + p * C + 4 * c4), gv = ld4(g + p * C + 4 * c4);
+    const float4 yv = ld4(y + p * C + 4 * c4);
+    float4 gv = ld4(g + p * C + 4 * c4);
+    if (pa.gp != nullptr) { const float4 q = pool_adj4<C>(pa, p, c4); gv.x += q.x; gv.y += q.y; gv.z += q.z; gv.w += q.w; }
     const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
     const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
     const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const double* __restrict__ coef,
-                                                           size_t nquads, float* __restrict__ dy) {
+                                                           size_t nquads, float* __restrict__ dy, const PoolAdj pa) {
   constexpr int Q = C / 4;
   const int c4 = threadIdx.x % Q;   // 256 % Q == 0 and grid stride is a multiple of 256
   const float4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4);
@@ -149,7 +165,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < 4; ++j) { sd[j] = coef[4 * c4 + j]; k1[j] = coef[C + 4 * c4 + j]; k0[j] = coef[2 * C + 4 * c4 + j]; }
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nquads; e += (size_t)gridDim.x * 256) {
-    const float4 yv = ld4(y + e * 4), gv = ld4(g + e * 4);
+    const float4 yv = ld4(y + e * 4);
+    float4 gv = ld4(g + e * 4);
+    if (pa.gp != nullptr) { const float4 q = pool_adj4<C>(pa, e / Q, c4); gv.x += q.x; gv.y += q.y; gv.z += q.z; gv.w += q.w; }
     float4 o;
     o.x = (float)fma(sd[0], (double)(fmaf(yv.x, sc.x, sh.x) > 0.f ? gv.x : 0.f), fma(k1[0], (double)yv.x, k0[0]));
     o.y = (float)fma(sd[1], (double)(fmaf(yv.y, sc.y, sh.y) > 0.f ? gv.y : 0.f), fma(k1[1], (double)yv.y, k0[1]));
@@ -188,11 +206,14 @@ int launch_bn_eval_coeffs(const float* params, const float* running, float eps, 
 }
 
 int launch_bn_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
-                         const float* invstd, int C, size_t npix, float* partials, int nblk, hipStream_t s) {
+                         const float* invstd, int C, size_t npix, float* partials, int nblk, hipStream_t s, const float* gp,
+                         int H, int W) {
+  if (gp != nullptr && (H < 2 || W < 2 || H % 2 || W % 2 || npix % ((size_t)H * W))) return SIFSR_ERR_SHAPE;
+  const PoolAdj pa{gp, H, W};
   switch (C) {
-    case 16: hipLaunchKernelGGL((bn_bwd_reduce_kernel<16>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials); break;
-    case 32: hipLaunchKernelGGL((bn_bwd_reduce_kernel<32>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials); break;
-    case 64: hipLaunchKernelGGL((bn_bwd_reduce_kernel<64>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials); break;
+    case 16: hipLaunchKernelGGL((bn_bwd_reduce_kernel<16>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa); break;
+    case 32: hipLaunchKernelGGL((bn_bwd_reduce_kernel<32>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa); break;
+    case 64: hipLaunchKernelGGL((bn_bwd_reduce_kernel<64>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa); break;
     default: return SIFSR_ERR_SHAPE;
   }
   SIFSR_LAUNCH_CHECK();
@@ -208,14 +229,16 @@ int launch_bn_bwd_finalize(const float* partials, int nblk, int C, double count,
 }
 
 int launch_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, const double* coef,
-                        int C, size_t npix, float* dy, hipStream_t s) {
+                        int C, size_t npix, float* dy, hipStream_t s, const float* gp, int H, int W) {
+  if (gp != nullptr && (H < 2 || W < 2 || H % 2 || W % 2 || npix % ((size_t)H * W))) return SIFSR_ERR_SHAPE;
+  const PoolAdj pa{gp, H, W};
   const size_t nquads = npix * (size_t)C / 4;
   size_t blocks = (nquads + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   switch (C) {
-    case 16: hipLaunchKernelGGL((bn_bwd_apply_kernel<16>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, coef, nquads, dy); break;
-    case 32: hipLaunchKernelGGL((bn_bwd_apply_kernel<32>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, coef, nquads, dy); break;
-    case 64: hipLaunchKernelGGL((bn_bwd_apply_kernel<64>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, coef, nquads, dy); break;
+    case 16: hipLaunchKernelGGL((bn_bwd_apply_kernel<16>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, coef, nquads, dy, pa); break;
+    case 32: hipLaunchKernelGGL((bn_bwd_apply_kernel<32>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, coef, nquads, dy, pa); break;
+    case 64: hipLaunchKernelGGL((bn_bwd_apply_kernel<64>), dim3((int)blocks), dim3(256), 0, s, g, y, scale, shift, coef, nquads, dy, pa); break;
     default: return SIFSR_ERR_SHAPE;
   }
   SIFSR_LAUNCH_CHECK();

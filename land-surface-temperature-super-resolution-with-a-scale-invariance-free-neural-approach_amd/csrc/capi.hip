@@ -165,12 +165,12 @@ int sifsr_bn_finalize(const float* stat_partials, int nblk, int C, double count,
 }
 int sifsr_bn_relu_bwd(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
                       const float* invstd, int C, size_t npix, float* partials, int nblk, float* dgamma, float* dbeta,
-                      double* coef, float* dy, void* stream) {
-  int rc = launch_bn_bwd_reduce(g, y, scale, shift, mean, invstd, C, npix, partials, nblk, S(stream));
+                      double* coef, float* dy, const float* gpool, int H, int W, void* stream) {
+  int rc = launch_bn_bwd_reduce(g, y, scale, shift, mean, invstd, C, npix, partials, nblk, S(stream), gpool, H, W);
   if (rc) return rc;
   rc = launch_bn_bwd_finalize(partials, nblk, C, (double)npix, scale, mean, invstd, dgamma, dbeta, coef, S(stream));
   if (rc) return rc;
-  return launch_bn_bwd_apply(g, y, scale, shift, coef, C, npix, dy, S(stream));
+  return launch_bn_bwd_apply(g, y, scale, shift, coef, C, npix, dy, S(stream), gpool, H, W);
 }
 
 int sifsr_bnrelu_pool2(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W, int C, void* stream) {

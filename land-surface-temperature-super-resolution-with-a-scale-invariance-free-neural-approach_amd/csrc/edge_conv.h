@@ -28,12 +28,15 @@ int launch_bn_finalize(const float* partials, int nblk, int C, double count, con
                        float* scale, float* shift, hipStream_t s);
 // eval: scale/shift from the running statistics of all 17 layers in one launch
 int launch_bn_eval_coeffs(const float* params, const float* running, float eps, float* scale, float* shift, hipStream_t s);
+// gp != nullptr: the AvgPool2d(2,2) adjoint of the half-resolution gradient gp (image H x W at full resolution) is
+// added to g on the fly in both passes:  g_eff = g + 0.25 * gp[y/2][x/2]
 int launch_bn_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
-                         const float* invstd, int C, size_t npix, float* partials, int nblk, hipStream_t s);
+                         const float* invstd, int C, size_t npix, float* partials, int nblk, hipStream_t s,
+                         const float* gp = nullptr, int H = 0, int W = 0);
 int launch_bn_bwd_finalize(const float* partials, int nblk, int C, double count, const float* scale, const float* mean,
                            const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s);
 int launch_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, const double* coef,
-                        int C, size_t npix, float* dy, hipStream_t s);
+                        int C, size_t npix, float* dy, hipStream_t s, const float* gp = nullptr, int H = 0, int W = 0);
 int launch_nbt_increment(long long* nbt, int n, hipStream_t s);
 
 // ---- resample.hip ---- (all NHWC, C % 4 == 0; scale == nullptr => input used as stored)

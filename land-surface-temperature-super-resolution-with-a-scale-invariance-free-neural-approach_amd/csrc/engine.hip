@@ -185,19 +185,21 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
 }
 
 // BatchNorm+ReLU backward of unit l: g (grad w.r.t. relu(bn(y_l))) -> dy (grad w.r.t. y_l); dgamma/dbeta -> grads
-int bn_unit_bwd(const Ctx& c, int l, const float* g, float* dy, float* grads) {
+// gp != nullptr: g is completed on the fly by the AvgPool adjoint of the half-resolution gradient gp (bn.hip PoolAdj)
+int bn_unit_bwd(const Ctx& c, int l, const float* g, float* dy, float* grads, const float* gp = nullptr) {
   const LayerInfo& L = c.nt.L[l];
+  const int lh = c.lvH(L.level), lw = c.lvW(L.level);
   const size_t npix = c.lay.npix[L.level];
   size_t nb = npix / 256;
   const int nblk = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
   const float* y = c.f(c.lay.y[l]);
   SIFSR_TRY(launch_bn_bwd_reduce(g, y, c.scale(l), c.shift(l), c.f(c.lay.mean) + L.ch_off, c.f(c.lay.invstd) + L.ch_off,
-                                 L.cout, npix, c.f(c.lay.partials), nblk, c.s));
+                                 L.cout, npix, c.f(c.lay.partials), nblk, c.s, gp, lh, lw));
   SIFSR_TRY(launch_bn_bwd_finalize(c.f(c.lay.partials), nblk, L.cout, (double)npix, c.scale(l), c.f(c.lay.mean) + L.ch_off,
                                    c.f(c.lay.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
                                    reinterpret_cast<double*>(c.f(c.lay.coef)), c.s));
   SIFSR_TRY(launch_bn_bwd_apply(g, y, c.scale(l), c.shift(l), reinterpret_cast<const double*>(c.f(c.lay.coef)), L.cout,
-                                npix, dy, c.s));
+                                npix, dy, c.s, gp, lh, lw));
   return SIFSR_OK;
 }
 
@@ -364,8 +366,10 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   static const int pc[3] = {16, 32, 64};
   for (int k = 2; k >= 0; --k) {
     const int la = enc_a[k], lb = enc_b[k], lc = enc_c[k], lp = enc_prev[k];
-    // lastconv: input R_k = P_k + relu(bn(y_b)); its gradient is both g(a_b) and part of g(P_k)
-    SIFSR_TRY(bn_unit_bwd(c, lc, c.f(w.g[lc]), c.f(w.g[lc]), grads));
+    // lastconv: input R_k = P_k + relu(bn(y_b)); its gradient is both g(a_b) and part of g(P_k).
+    // y_c also feeds the next pooling stage (k < 2): that AvgPool adjoint (of gP[k+1], computed in the previous
+    // iteration) is folded into this BatchNorm backward instead of a separate accumulate pass over g[lc].
+    SIFSR_TRY(bn_unit_bwd(c, lc, c.f(w.g[lc]), c.f(w.g[lc]), grads, k < 2 ? c.f(w.gP[k + 1]) : nullptr));
     SIFSR_TRY(conv_unit_wgrad(c, lc, src_raw(c.f(w.R[k]), pc[k]), src_none(), c.f(w.g[lc]), grads));
     SIFSR_TRY(conv_unit_dgrad(c, lc, c.f(w.g[lc]), c.f(w.g[lb]), pc[k], pc[k], nullptr, 0, nullptr));
     // residual DoubleConvolution (g[lb] must survive as the skip gradient -> dy goes to dyB)
@@ -375,12 +379,12 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), c.f(w.g[la]), grads));
     SIFSR_TRY(conv_unit_wgrad(c, la, src_raw(c.f(w.P[k]), pc[k]), src_none(), c.f(w.g[la]), grads));
     SIFSR_TRY(conv_unit_dgrad(c, la, c.f(w.g[la]), c.f(w.gP[k]), pc[k], pc[k], nullptr, 0, c.f(w.g[lb])));
-    // AvgPool adjoint, accumulated onto the skip gradient written by the decoder
-    SIFSR_TRY(launch_pool2_bwd(c.f(w.gP[k]), c.f(w.g[lp]), B, c.lvH(k), c.lvW(k), pc[k], 1, s));
+    // AvgPool adjoint of gP[k] onto the skip gradient g[lp]: folded into the BatchNorm backward of lp (above / below)
+    (void)lp;
   }
 
   // inbloc
-  SIFSR_TRY(bn_unit_bwd(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN3]), grads));
+  SIFSR_TRY(bn_unit_bwd(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN3]), grads, c.f(w.gP[0])));
   SIFSR_TRY(conv_unit_wgrad(c, L_IN3, src_act(c, L_IN0), src_none(), c.f(w.g[L_IN3]), grads));
   SIFSR_TRY(conv_unit_dgrad(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), 16, 16, nullptr, 0, nullptr));
   // first layer: no input gradient, so dy(L_IN0) is consumed by the weight gradient alone and is formed on the

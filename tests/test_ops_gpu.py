@@ -215,10 +215,21 @@ def test_batchnorm_fwd_bwd(L, C):
     dgam, dbet = (torch.empty(C, device="cuda") for _ in range(2))
     coef = torch.empty(3 * C, dtype=torch.float64, device="cuda")
     dy = torch.empty(B, H, W, C, device="cuda")
-    L.call("sifsr_bn_relu_bwd", dev(nhwc(g)), yd, scale, shift, mean, invstd, C, npix, partials, nb, dgam, dbet, coef, dy, S())
+    L.call("sifsr_bn_relu_bwd", dev(nhwc(g)), yd, scale, shift, mean, invstd, C, npix, partials, nb, dgam, dbet, coef, dy,
+           None, 0, 0, S())
     torch.cuda.synchronize()
     assert rel_err(dgam.cpu(), gg_ref) < TOL and rel_err(dbet.cpu(), gb_ref) < TOL
     assert rel_err(nchw(dy.cpu()), gy_ref) < TOL
+
+    # the activation also feeds AvgPool2d(2,2): the pooled tensor's gradient is folded in on the fly
+    a2 = F.relu(F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5))
+    gp = rnd(rs, B, C, H // 2, W // 2)
+    gy2, gg2, gb2 = torch.autograd.grad((a2 * g).sum() + (F.avg_pool2d(a2, 2, 2) * gp).sum(), [y, gamma, beta])
+    L.call("sifsr_bn_relu_bwd", dev(nhwc(g)), yd, scale, shift, mean, invstd, C, npix, partials, nb, dgam, dbet, coef, dy,
+           dev(nhwc(gp)), H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(dgam.cpu(), gg2) < TOL and rel_err(dbet.cpu(), gb2) < TOL
+    assert rel_err(nchw(dy.cpu()), gy2) < TOL
 
 
 @pytest.mark.parametrize("C", [16, 64])

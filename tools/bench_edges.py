@@ -50,4 +50,4 @@ timeit("conv_in_bn_relu_bwd (fused head)", lambda: L.call("sifsr_conv_in_bn_relu
 timeit("conv_in_fwd", lambda: L.call("sifsr_conv_in_fwd", x, w_in, dy, part, B, H, W, S()), T + T / 8)
 timeit("conv_out_fwd", lambda: L.call("sifsr_conv_out_fwd", y, scale, shift, w_out, b_out, sr, B, H, W, S()), T + T / 16)
 timeit("bn_relu_bwd C=16", lambda: L.call("sifsr_bn_relu_bwd", gg, y, scale, shift, mean, invstd, 16, B * H * W, scratch, 1024,
-       dgam, dbet, coef, dy, S()), 5 * T)
+       dgam, dbet, coef, dy, None, 0, 0, S()), 5 * T)
