@@ -51,6 +51,9 @@ int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStr
 int wgrad_nbi_chunk(const WgradArgs& a, int cin);   // 16-channel blocks per Cin chunk (blockIdx.y)
 int launch_wgrad_reduce(const float* slabs, int nblk, int cin, int cout, int nbi_chunk, float* dw_oihw, hipStream_t s);
 size_t wgrad_slab_floats(int cin, int cout);   // floats per block
+// All layers' slab reductions in ONE launch (end of the backward pass) instead of one latency-bound launch per layer.
+struct WgradReduceJob { size_t slab_off; int nblk, cin, cout, nbi_chunk, w_off; };
+int launch_wgrad_reduce_batched(const float* ws, const WgradReduceJob* jobs, int njobs, float* grads, hipStream_t s);
 
 // dgrad: replicate-padding adjoint fold for the border pixels (adds to g_in).  wdg_layer = the layer's
 // dgrad weight pack [fragment order | tap-major] written by pack_weights.

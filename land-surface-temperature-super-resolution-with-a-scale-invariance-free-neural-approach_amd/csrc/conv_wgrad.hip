@@ -245,6 +245,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+struct ReduceTable {
+  unsigned long long slab_off[16];
+  int nblk[16], cin[16], cout[16], nbi_chunk[16], w_off[16], el_log2[16], blk_start[17];
+  int njobs;
+};
+
+// Batched form of wgrad_reduce_kernel: block -> (layer, EL consecutive slab elements); EL per layer as above.
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const float* __restrict__ ws, const ReduceTable tb,
+                                                                   float* __restrict__ grads) {
+  __shared__ double part[256];
+  int l = 0;
+  while (l + 1 < tb.njobs && (int)blockIdx.x >= tb.blk_start[l + 1]) ++l;
+  const int lg = tb.el_log2[l], EL = 1 << lg, GR = 256 >> lg;
+  const int cin = tb.cin[l], cout = tb.cout[l], nblk = tb.nblk[l], nbi_chunk = tb.nbi_chunk[l];
+  const int n = 9 * cin * cout;
+  const float* slabs = ws + tb.slab_off[l];
+  const int jl = threadIdx.x & (EL - 1), grp = threadIdx.x >> lg;
+  const int j = ((int)blockIdx.x - tb.blk_start[l]) * EL + jl;
+  double s = 0.0;
+  if (j < n)
+    for (int k = grp; k < nblk; k += GR) s += (double)slabs[(size_t)k * n + j];
+  part[grp * EL + jl] = s;
+  __syncthreads();
+  for (int st = GR / 2; st > 0; st >>= 1) {
+    if (grp < st) part[grp * EL + jl] += part[(grp + st) * EL + jl];
+    __syncthreads();
+  }
+  if (grp == 0 && j < n) {
+    const int r = j & 3, lane = (j >> 2) & 63;
+    const int rest = j >> 8;
+    const int t = rest % 9, r2 = rest / 9;
+    const int NBO = cout / 16;
+    const int nbi = r2 % nbi_chunk, r3 = r2 / nbi_chunk;
+    const int nbo = r3 % NBO, chunk = r3 / NBO;
+    const int co = 16 * nbo + 4 * (lane >> 4) + r, ci = 16 * (chunk * nbi_chunk + nbi) + (lane & 15);
+    grads[tb.w_off[l] + (co * cin + ci) * 9 + t] = (float)part[jl];
+  }
+}
+
 template <int NBO, int NBI>
 int launch_wgrad_t(const WgradArgs& a, int chunks, int nblk, hipStream_t s) {
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
@@ -296,6 +335,25 @@ int launch_wgrad_reduce(const float* slabs, int nblk, int cin, int cout, int nbi
     hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3((n + 15) / 16), dim3(256), 0, s, slabs, nblk, cin, cout, nbi_chunk, dw_oihw);
   else
     hipLaunchKernelGGL((wgrad_reduce_kernel<32>), dim3((n + 31) / 32), dim3(256), 0, s, slabs, nblk, cin, cout, nbi_chunk, dw_oihw);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_wgrad_reduce_batched(const float* ws, const WgradReduceJob* jobs, int njobs, float* grads, hipStream_t s) {
+  if (njobs < 1 || njobs > 16) return SIFSR_ERR_ARG;
+  ReduceTable tb;
+  int blk = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const int n = 9 * jobs[i].cin * jobs[i].cout;
+    const int lg = n <= 2304 ? 2 : (n <= 4608 ? 3 : (n <= 9216 ? 4 : 5));
+    tb.slab_off[i] = jobs[i].slab_off; tb.nblk[i] = jobs[i].nblk; tb.cin[i] = jobs[i].cin; tb.cout[i] = jobs[i].cout;
+    tb.nbi_chunk[i] = jobs[i].nbi_chunk; tb.w_off[i] = jobs[i].w_off; tb.el_log2[i] = lg;
+    tb.blk_start[i] = blk;
+    blk += (n + (1 << lg) - 1) >> lg;
+  }
+  tb.blk_start[njobs] = blk;
+  tb.njobs = njobs;
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(blk), dim3(256), 0, s, ws, tb, grads);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

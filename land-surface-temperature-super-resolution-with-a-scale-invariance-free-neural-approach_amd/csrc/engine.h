@@ -18,7 +18,8 @@ struct WsLayout {
   size_t g[SIFSR_NUM_BN_LAYERS];          // grad w.r.t. relu(bn(y_l)), overwritten in place by dy_l
   size_t dyB[3];                          // dy of the residual blocks' second conv
   size_t gP[3], gU[3];
-  size_t slabs;                           // wgrad per-workgroup partial dW (scratch)
+  size_t slabs;                           // thin-layer per-workgroup partials (scratch)
+  size_t slab_l[SIFSR_NUM_BN_LAYERS];     // wgrad per-workgroup partial dW of every MFMA layer (reduced together at the end)
   size_t total;
 };
 

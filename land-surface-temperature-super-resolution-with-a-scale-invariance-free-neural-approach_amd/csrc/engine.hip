@@ -97,13 +97,13 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
     w.dyB[0] = take(16 * N[1]); w.dyB[1] = take(32 * N[2]); w.dyB[2] = take(64 * N[3]);
     for (int k = 0; k < 3; ++k) w.gP[k] = take(pc[k] * N[k + 1]);
     w.gU[0] = take(64 * N[2]); w.gU[1] = take(32 * N[1]); w.gU[2] = take(16 * N[0]);
-    size_t maxslab = 1024 * 288;   // edge-layer partials
+    w.slabs = take(1024 * 288);   // edge-layer partials
+    w.slab_l[0] = 0;
     for (int l = 1; l < SIFSR_NUM_BN_LAYERS; ++l) {
       const int ntiles = (int)(N[nt.L[l].level] / 128);
-      const size_t n = (size_t)wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles) * 9 * nt.L[l].cin * nt.L[l].cout;   // upper bound over chunkings
-      maxslab = n > maxslab ? n : maxslab;
+      // upper bound over chunkings (x-dim blocks * chunks <= blocks at one chunk)
+      w.slab_l[l] = take((size_t)wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles) * 9 * nt.L[l].cin * nt.L[l].cout);
     }
-    w.slabs = take(maxslab);
   }
   w.total = off;
   return SIFSR_OK;
@@ -121,6 +121,8 @@ struct Ctx {
   const float* params;
   int B, H, W;
   hipStream_t s;
+  WgradReduceJob* jobs = nullptr;   // backward: slab reductions deferred to one batched launch
+  int* njobs = nullptr;
   int lvH(int lv) const { return H >> lv; }
   int lvW(int lv) const { return W >> lv; }
   float* f(size_t off) const { return ws + off; }
@@ -208,7 +210,7 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
   const LayerInfo& L = c.nt.L[l];
   WgradArgs a;
   a.src[0] = s0; a.src[1] = s1;
-  a.dy = dy; a.slabs = c.f(c.lay.slabs);
+  a.dy = dy; a.slabs = c.f(c.lay.slab_l[l]);
   a.B = c.B; a.H = c.lvH(L.level); a.W = c.lvW(L.level);
   a.NQ = L.cin / 16;
   a.ntiles = c.B * (a.H / 8) * (a.W / 16);
@@ -218,7 +220,12 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
     ProfScope ps(l, 3, c.s);
     SIFSR_TRY(launch_conv3x3_wgrad(a, L.cin, L.cout, nblk, c.s));
   }
-  SIFSR_TRY(launch_wgrad_reduce(a.slabs, nblk, L.cin, L.cout, nbi, grads + L.w_off, c.s));
+  if (c.jobs != nullptr) {
+    WgradReduceJob& j = c.jobs[(*c.njobs)++];
+    j.slab_off = c.lay.slab_l[l]; j.nblk = nblk; j.cin = L.cin; j.cout = L.cout; j.nbi_chunk = nbi; j.w_off = L.w_off;
+  } else {
+    SIFSR_TRY(launch_wgrad_reduce(a.slabs, nblk, L.cin, L.cout, nbi, grads + L.w_off, c.s));
+  }
   return SIFSR_OK;
 }
 
@@ -323,6 +330,9 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   if (ws_floats < c.lay.total) return SIFSR_ERR_WORKSPACE;
   const NetTable& nt = c.nt;
   const WsLayout& w = c.lay;
+  WgradReduceJob jobs[16];
+  int njobs = 0;
+  c.jobs = jobs; c.njobs = &njobs;
 
   // outlay backward fused with the BatchNorm+ReLU backward of ub3.convbloc.bloc.3 (fused_edges.hip): the outlay
   // input gradient is recomputed from dsr in both passes instead of being stored; dy(L_U3B) -> g[L_U3B]
@@ -406,6 +416,8 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
                                          reinterpret_cast<const double*>(c.f(w.coef)), c.f(w.slabs), nblk,
                                          grads + L.w_off, B, H, W, s));
   }
+  // all 16 MFMA layers' weight-gradient slabs -> OIHW gradients, one launch
+  SIFSR_TRY(launch_wgrad_reduce_batched(ws, jobs, njobs, grads, s));
   return SIFSR_OK;
 }
 
