@@ -247,32 +247,40 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 struct ReduceTable {
   unsigned long long slab_off[16];
-  int nblk[16], cin[16], cout[16], nbi_chunk[16], w_off[16], el_log2[16], blk_start[17];
+  int nblk[16], cin[16], cout[16], nbi_chunk[16], w_off[16], blk_start[17];
   int njobs;
 };
 
-// Batched form of wgrad_reduce_kernel: block -> (layer, EL consecutive slab elements); EL per layer as above.
+// Batched form of the slab reduction (the slabs come from HBM here, not from a warm L2): block -> (layer, 32
+// consecutive slab elements = one 128-byte line per slab); 8 lanes x float4 cover the line, 32 lane groups walk
+// the slabs; float64 sums, fixed order; n = 9*cin*cout is a multiple of 32 for every layer.
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const float* __restrict__ ws, const ReduceTable tb,
                                                                    float* __restrict__ grads) {
-  __shared__ double part[256];
+  __shared__ double part[32][8][4];
   int l = 0;
   while (l + 1 < tb.njobs && (int)blockIdx.x >= tb.blk_start[l + 1]) ++l;
-  const int lg = tb.el_log2[l], EL = 1 << lg, GR = 256 >> lg;
   const int cin = tb.cin[l], cout = tb.cout[l], nblk = tb.nblk[l], nbi_chunk = tb.nbi_chunk[l];
   const int n = 9 * cin * cout;
   const float* slabs = ws + tb.slab_off[l];
-  const int jl = threadIdx.x & (EL - 1), grp = threadIdx.x >> lg;
-  const int j = ((int)blockIdx.x - tb.blk_start[l]) * EL + jl;
-  double s = 0.0;
-  if (j < n)
-    for (int k = grp; k < nblk; k += GR) s += (double)slabs[(size_t)k * n + j];
-  part[grp * EL + jl] = s;
+  const int jl = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int j4 = ((int)blockIdx.x - tb.blk_start[l]) * 32 + 4 * jl;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+  for (int k = grp; k < nblk; k += 32) {
+    const float4 v = ld4(slabs + (size_t)k * n + j4);
+    s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+  }
+  part[grp][jl][0] = s0; part[grp][jl][1] = s1; part[grp][jl][2] = s2; part[grp][jl][3] = s3;
   __syncthreads();
-  for (int st = GR / 2; st > 0; st >>= 1) {
-    if (grp < st) part[grp * EL + jl] += part[(grp + st) * EL + jl];
+  for (int st = 16; st > 0; st >>= 1) {
+    if (grp < st) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[grp][jl][r] += part[grp + st][jl][r];
+    }
     __syncthreads();
   }
-  if (grp == 0 && j < n) {
+  if (threadIdx.x < 32) {
+    const int j = ((int)blockIdx.x - tb.blk_start[l]) * 32 + threadIdx.x;
     const int r = j & 3, lane = (j >> 2) & 63;
     const int rest = j >> 8;
     const int t = rest % 9, r2 = rest / 9;
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const float* 
     const int nbi = r2 % nbi_chunk, r3 = r2 / nbi_chunk;
     const int nbo = r3 % NBO, chunk = r3 / NBO;
     const int co = 16 * nbo + 4 * (lane >> 4) + r, ci = 16 * (chunk * nbi_chunk + nbi) + (lane & 15);
-    grads[tb.w_off[l] + (co * cin + ci) * 9 + t] = (float)part[jl];
+    grads[tb.w_off[l] + (co * cin + ci) * 9 + t] = (float)part[0][threadIdx.x >> 2][threadIdx.x & 3];
   }
 }
 
@@ -345,11 +353,11 @@ int launch_wgrad_reduce_batched(const float* ws, const WgradReduceJob* jobs, int
   int blk = 0;
   for (int i = 0; i < njobs; ++i) {
     const int n = 9 * jobs[i].cin * jobs[i].cout;
-    const int lg = n <= 2304 ? 2 : (n <= 4608 ? 3 : (n <= 9216 ? 4 : 5));
+    if (n % 32 || jobs[i].slab_off % 4) return SIFSR_ERR_SHAPE;
     tb.slab_off[i] = jobs[i].slab_off; tb.nblk[i] = jobs[i].nblk; tb.cin[i] = jobs[i].cin; tb.cout[i] = jobs[i].cout;
-    tb.nbi_chunk[i] = jobs[i].nbi_chunk; tb.w_off[i] = jobs[i].w_off; tb.el_log2[i] = lg;
+    tb.nbi_chunk[i] = jobs[i].nbi_chunk; tb.w_off[i] = jobs[i].w_off;
     tb.blk_start[i] = blk;
-    blk += (n + (1 << lg) - 1) >> lg;
+    blk += n / 32;
   }
   tb.blk_start[njobs] = blk;
   tb.njobs = njobs;
