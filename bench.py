@@ -44,6 +44,21 @@ ROOFLINE_KERNELS = {
 }
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json, written by
+    tools/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    for f in reversed(files):
+        try:
+            t = json.load(open(f))["per_launch"].get(kernel)
+        except (OSError, ValueError, KeyError):
+            continue
+        if t:
+            return round(t["bytes"]), os.path.basename(f)
+    return None, None
+
+
 def cpu_baseline(kind, alpha, gamma, lr, mean, std, target_seconds=15.0):
     """Time the oracle's train step (fwd + loss + bwd + Adam) on the host cores; bounded sample."""
     from oracle import sif_oracle as O
@@ -142,9 +157,11 @@ def main():
         kavg_ms = kms.value / max(1, kcount.value)
         kt = kflops * args.batch / (kavg_ms * 1e-3) / 1e12 if kavg_ms > 0 else 0.0
         step_tf = TRAIN_FLOPS_PER_PATCH * per_gpu / 1e12
+        traffic, traffic_src = measured_traffic(args.roofline_kernel)
         out["roofline"] = {
             "bound": "mfma", "kernel": args.roofline_kernel, "achieved": round(kt, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(kt / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(kt / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes/launch (PMC)", "traffic_source": traffic_src,
             "kernel_avg_ms": round(kavg_ms, 4), "kernel_launches_timed": kcount.value,
             "step": {"achieved": round(step_tf, 2), "frac": round(step_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                      "hbm_GBs_algorithmic": round(TRAIN_BYTES_PER_PATCH * per_gpu / 1e9, 1)},

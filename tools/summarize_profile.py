@@ -45,6 +45,36 @@ for r in rows[:30]:
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 
+# ---- per-launch HBM traffic of the kernels bench.py can select as its roofline kernel ----
+# The n-th launch of a kernel inside a step is identified by dispatch order (the schedule is static):
+#   fwd <1,false>: [inbloc.3, db1.res.0, db1.res.3, ub2.3, ub3.0, ub3.3]; dgrad <1,true> (backward order):
+#   [ub3.3, ub2.3, db1.lastconv?...] -- only the unambiguous first/last launches are exported.
+def per_launch(kind, pattern, nth, per_step):
+    f = glob.glob(f"{src}/pmc_{kind}/*/*counter_collection.csv")
+    if not f:
+        return None
+    vals = [float(r["Counter_Value"]) for r in sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Dispatch_Id"]))
+            if pattern in r["Kernel_Name"]]
+    if len(vals) < per_step * steps:
+        return None
+    picks = [vals[i * per_step + nth] for i in range(steps)]
+    return sum(picks) / len(picks)
+
+
+import json
+traffic = {}
+for name, pattern, nth, per_step in [
+        ("fwd_16x16_256", "conv3x3_mfma_kernel<1, false>", 0, 6),     # inbloc.bloc.3: first <1,false> launch of a step
+        ("fwd_32x16_256", "conv3x3_mfma_kernel<1, false>", 4, 6),     # ub3.convbloc.bloc.0
+        ("dgrad_16x16_256", "conv3x3_mfma_kernel<1, true>", 0, 5),    # ub3.convbloc.bloc.3: first dgrad of the backward
+        ("wgrad_16x16_256", "conv3x3_wgrad_kernel<1, 1>", 0, 5)]:     # ub3.convbloc.bloc.3
+    fr, wr = per_launch("fetch", pattern, nth, per_step), per_launch("write", pattern, nth, per_step)
+    if fr is not None and wr is not None:
+        traffic[name] = {"read_bytes": 2 * fr * 1024, "write_bytes": wr * 1024, "bytes": 2 * fr * 1024 + wr * 1024}
+json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tag {tag}; FETCH_SIZE doubled (gfx950)",
+           "per_launch": traffic}, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
+print(json.dumps(traffic, indent=1))
+
 # ---- category roll-up ----
 cats = collections.OrderedDict([
     ("conv fwd (MFMA)", lambda k: "conv3x3_mfma_kernel" in k and "false" in k),
