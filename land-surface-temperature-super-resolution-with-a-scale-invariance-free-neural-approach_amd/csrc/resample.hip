@@ -142,6 +142,112 @@ __global__ void up2x_bwd_kernel(const float* __restrict__ gu, float* __restrict_
   }
 }
 
+// ---- tiled forms for C in {16, 32, 64} (the model's channel counts) ----
+// Upsample: one workgroup = 16x16 output pixels.  Their <= 10x10 source pixels are loaded, BatchNorm+ReLU'd ONCE and
+// kept in LDS (the per-output form above transforms every source pixel four times and spends most of its time on
+// 64-bit index arithmetic); the blend itself is the same expression, so results are bit-identical.
+template <int C>
+__global__ __launch_bounds__(256) void bnrelu_up2x_tile_kernel(const float* __restrict__ y, const float* scale,
+                                                               const float* shift, float* __restrict__ out, int Hin,
+                                                               int Win) {
+  constexpr int Q = C / 4, SR = 10;
+  __shared__ float4 src[SR * SR * Q];
+  const int tid = threadIdx.x;
+  const int Ho = 2 * Hin, Wo = 2 * Win;
+  const int ox0 = blockIdx.x * 16, oy0 = blockIdx.y * 16, b = blockIdx.z;
+  int sy0, sx0, t1; float f0, f1;
+  up_coord(oy0, Hin, Ho, sy0, t1, f0, f1);
+  up_coord(ox0, Win, Wo, sx0, t1, f0, f1);
+  for (int e = tid; e < SR * SR * Q; e += 256) {
+    const int c4 = e % Q, p = e / Q;
+    const int py = p / SR, px = p - py * SR;
+    const int gy = min(sy0 + py, Hin - 1), gx = min(sx0 + px, Win - 1);
+    src[e] = maybe_bnrelu(ld4(y + ((size_t)(b * Hin + gy) * Win + gx) * C + 4 * c4), scale, shift, 4 * c4);
+  }
+  __syncthreads();
+  for (int e = tid; e < 256 * Q; e += 256) {
+    const int c4 = e % Q, p = e / Q;
+    const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+    if (oy >= Ho || ox >= Wo) continue;
+    int y0, y1, x0, x1; float hy0, hy1, hx0, hx1;
+    up_coord(oy, Hin, Ho, y0, y1, hy0, hy1);
+    up_coord(ox, Win, Wo, x0, x1, hx0, hx1);
+    const float4 v00 = src[((y0 - sy0) * SR + (x0 - sx0)) * Q + c4], v01 = src[((y0 - sy0) * SR + (x1 - sx0)) * Q + c4];
+    const float4 v10 = src[((y1 - sy0) * SR + (x0 - sx0)) * Q + c4], v11 = src[((y1 - sy0) * SR + (x1 - sx0)) * Q + c4];
+    float4 o;
+    o.x = hy0 * (hx0 * v00.x + hx1 * v01.x) + hy1 * (hx0 * v10.x + hx1 * v11.x);
+    o.y = hy0 * (hx0 * v00.y + hx1 * v01.y) + hy1 * (hx0 * v10.y + hx1 * v11.y);
+    o.z = hy0 * (hx0 * v00.z + hx1 * v01.z) + hy1 * (hx0 * v10.z + hx1 * v11.z);
+    o.w = hy0 * (hx0 * v00.w + hx1 * v01.w) + hy1 * (hx0 * v10.w + hx1 * v11.w);
+    st4(out + ((size_t)(b * Ho + oy) * Wo + ox) * C + 4 * c4, o);
+  }
+}
+
+// Adjoint, separable through LDS: one workgroup = 8x8 low-res pixels x 16 channels; the 19x19 high-res pixels that
+// can reach them (rows 2i-2 .. 2i+2 per low-res row i) are read ONCE (the gather form above reads every high-res
+// pixel from ~4 threads), reduced horizontally, then vertically.  Deterministic (gather, fixed order).
+template <int C>
+__global__ __launch_bounds__(256) void up2x_bwd_tile_kernel(const float* __restrict__ gu, float* __restrict__ g, int Hin,
+                                                            int Win) {
+  constexpr int TL = 8, HR = 2 * TL + 3, NCH = C / 16;
+  __shared__ float4 hi[HR * HR * 4];
+  __shared__ float4 tmp[HR * TL * 4];
+  __shared__ float wxs[TL][5], wys[TL][5];
+  const int tid = threadIdx.x;
+  const int Ho = 2 * Hin, Wo = 2 * Win;
+  const int ix0 = blockIdx.x * TL, iy0 = blockIdx.y * TL;
+  const int b = blockIdx.z / NCH, ch0 = (blockIdx.z % NCH) * 16;
+  if (tid < 2 * TL * 5) {
+    const bool isy = tid >= TL * 5;
+    const int t = isy ? tid - TL * 5 : tid;
+    const int il = t / 5, k = t - il * 5;
+    const int i = (isy ? iy0 : ix0) + il, in = isy ? Hin : Win, on = isy ? Ho : Wo;
+    const int o = 2 * i - 2 + k;
+    float w = 0.f;
+    if (i < in && o >= 0 && o < on) {
+      int a0, a1; float l0, l1;
+      up_coord(o, in, on, a0, a1, l0, l1);
+      w = (a0 == i ? l0 : 0.f) + (a1 == i ? l1 : 0.f);
+    }
+    if (isy) wys[il][k] = w; else wxs[il][k] = w;
+  }
+  for (int e = tid; e < HR * HR * 4; e += 256) {
+    const int q = e & 3, p = e >> 2;
+    const int py = p / HR, px = p - py * HR;
+    const int oy = 2 * iy0 - 2 + py, ox = 2 * ix0 - 2 + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) v = ld4(gu + ((size_t)(b * Ho + oy) * Wo + ox) * C + ch0 + 4 * q);
+    hi[e] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < HR * TL * 4; e += 256) {
+    const int q = e & 3, p = e >> 2;
+    const int py = p / TL, il = p - py * TL;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float w = wxs[il][k];
+      const float4 v = hi[(py * HR + 2 * il + k) * 4 + q];
+      acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+    }
+    tmp[e] = acc;
+  }
+  __syncthreads();
+  {
+    const int q = tid & 3, p = tid >> 2;
+    const int il_y = p / TL, il_x = p - il_y * TL;
+    const int iy = iy0 + il_y, ix = ix0 + il_x;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float w = wys[il_y][k];
+      const float4 v = tmp[((2 * il_y + k) * TL + il_x) * 4 + q];
+      acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+    }
+    if (iy < Hin && ix < Win) st4(g + ((size_t)(b * Hin + iy) * Win + ix) * C + ch0 + 4 * q, acc);
+  }
+}
+
 inline int grid_for(size_t n) {
   size_t b = (n + 255) / 256;
   return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
@@ -164,6 +270,14 @@ int launch_bnrelu_add(const float* p, const float* y, const float* scale, const 
 }
 int launch_bnrelu_up2x(const float* y, const float* scale, const float* shift, float* out, int B, int Hin, int Win, int C, hipStream_t s) {
   if (C % 4) return SIFSR_ERR_SHAPE;
+  if ((C == 16 || C == 32 || C == 64) && B <= 65535 && Hin >= 2 && Win >= 2) {
+    const dim3 grid((2 * Win + 15) / 16, (2 * Hin + 15) / 16, B);
+    if (C == 16) hipLaunchKernelGGL((bnrelu_up2x_tile_kernel<16>), grid, dim3(256), 0, s, y, scale, shift, out, Hin, Win);
+    else if (C == 32) hipLaunchKernelGGL((bnrelu_up2x_tile_kernel<32>), grid, dim3(256), 0, s, y, scale, shift, out, Hin, Win);
+    else hipLaunchKernelGGL((bnrelu_up2x_tile_kernel<64>), grid, dim3(256), 0, s, y, scale, shift, out, Hin, Win);
+    SIFSR_LAUNCH_CHECK();
+    return SIFSR_OK;
+  }
   hipLaunchKernelGGL(bnrelu_up2x_kernel, dim3(grid_for((size_t)B * Hin * Win * C)), dim3(256), 0, s, y, scale, shift, out, B, Hin, Win, C);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
@@ -176,6 +290,14 @@ int launch_pool2_bwd(const float* gp, float* g, int B, int H, int W, int C, int 
 }
 int launch_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, hipStream_t s) {
   if (C % 4) return SIFSR_ERR_SHAPE;
+  if ((C == 16 || C == 32 || C == 64) && (size_t)B * (C / 16) <= 65535) {
+    const dim3 grid((Win + 7) / 8, (Hin + 7) / 8, B * (C / 16));
+    if (C == 16) hipLaunchKernelGGL((up2x_bwd_tile_kernel<16>), grid, dim3(256), 0, s, gu, g, Hin, Win);
+    else if (C == 32) hipLaunchKernelGGL((up2x_bwd_tile_kernel<32>), grid, dim3(256), 0, s, gu, g, Hin, Win);
+    else hipLaunchKernelGGL((up2x_bwd_tile_kernel<64>), grid, dim3(256), 0, s, gu, g, Hin, Win);
+    SIFSR_LAUNCH_CHECK();
+    return SIFSR_OK;
+  }
   hipLaunchKernelGGL(up2x_bwd_kernel, dim3(grid_for((size_t)B * Hin * Win * C / 4)), dim3(256), 0, s, gu, g, B, Hin, Win, C);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;

@@ -232,10 +232,10 @@ def test_batchnorm_fwd_bwd(L, C):
     assert rel_err(nchw(dy.cpu()), gy2) < TOL
 
 
-@pytest.mark.parametrize("C", [16, 64])
-def test_resample(L, C):
+@pytest.mark.parametrize("C,hw", [(16, (16, 24)), (64, (16, 24)), (32, (64, 64)), (16, (36, 20)), (8, (16, 24))])
+def test_resample(L, C, hw):
     rs = np.random.RandomState(4 + C)
-    B, H, W = 2, 16, 24
+    B, (H, W) = 2, hw
     yraw = rnd(rs, B, C, H, W)
     sc = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)); sh = rnd(rs, C, scale=0.3)
     a = F.relu(yraw * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
