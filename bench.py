@@ -24,6 +24,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL / IPC on this driver needs dmabuf handles (before any HIP init)
 
 import torch
 
