@@ -115,6 +115,7 @@ def main():
         return sifsr.train.train_step(model, opt, lst, lst_up, ndvi, stats, alpha, gamma, kind)
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -134,7 +135,7 @@ def main():
     L.call("sifsr_profile_read", ctypes.byref(kms), ctypes.byref(kcount))
     L.call("sifsr_profile_select", -1, 0)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     assert all(torch.isfinite(v) for v in losses), "non-finite loss"

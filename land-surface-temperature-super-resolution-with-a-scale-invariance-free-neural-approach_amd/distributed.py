@@ -23,13 +23,26 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SIFSR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if torch.cuda.is_available() and torch.cuda.device_count() > 0:
+        local = local % torch.cuda.device_count()   # rehearsals with more ranks than GPUs (gloo); identity on a full node
     return rank, world, local
+
+
+def _sum_all_reduce_(flat: torch.Tensor):
+    """Sum all-reduce in place.  RCCL reduces device memory directly; the gloo rehearsal path stages device
+    tensors through the host (gloo in this build has no device support)."""
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        host = flat.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
 
 def world_size() -> int:
@@ -46,7 +59,7 @@ def shard_range(n_items: int, rank: int, world: int):
 def allreduce_flat_(flat: torch.Tensor, average: bool = False):
     """In-place sum (or mean) all-reduce of one flat tensor; a no-op for world_size 1."""
     if world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        _sum_all_reduce_(flat)
         if average:
             flat.div_(world_size())
     return flat
@@ -62,7 +75,7 @@ def allreduce_gradients(model, optimizer=None):
     flat = model.flat_grad() if hasattr(model, "flat_grad") else None
     if flat is None:
         raise RuntimeError("no flat gradient: run backward first")
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    _sum_all_reduce_(flat)
     if optimizer is not None and hasattr(optimizer, "grad_scale"):
         optimizer.grad_scale = 1.0 / w
     else:
@@ -75,4 +88,9 @@ def broadcast_buffers(model, src: int = 0):
     if world_size() == 1:
         return
     for b in model.buffers():
-        dist.broadcast(b, src=src)
+        if b.is_cuda and dist.get_backend() == "gloo":
+            host = b.detach().cpu()
+            dist.broadcast(host, src=src)
+            b.copy_(host)
+        else:
+            dist.broadcast(b, src=src)
