@@ -99,7 +99,7 @@ def _hip_forward_backward(sifsr, sd, lst, lst_up, ndvi, alpha, gamma, kind):
     for n, p in m.named_parameters():
         g[n] = grads[off:off + p.numel()].view(p.shape).cpu()
         off += p.numel()
-    return sr.cpu(), (float(ds), float(pl), float(loss)), g, masks, m
+    return sr.cpu(), (float(ds), float(pl), float(loss.detach())), g, masks, m
 
 
 @pytest.mark.parametrize("kind", ["sr2", "sr1"])
@@ -297,3 +297,34 @@ def test_graph_captured_inference(sifsr, golden):
     out2 = gp(lst_up2.cuda(), ndvi2.cuda())
     ref2 = O.predict_tiles(sd, lst_up2, ndvi2, MEAN, STD)
     assert rel_err(out2, ref2) < TOL
+
+
+def test_non_square_patches(sifsr):
+    """128 x 384 patches: the tile grids are 8x24 / 4x12 / ... -- not powers of two, so every persistent kernel
+    takes its generic tile-index path and every level has border tiles on all four sides.  Forward, losses and
+    gradients (at the masks the HIP forward took) against the oracle."""
+    rs = np.random.RandomState(5)
+    B, H, W = 2, 128, 384
+    sd = O.synthetic_state(23)
+    lst = torch.from_numpy(rs.standard_normal((B, 1, H // 4, W // 4)).astype(np.float32))
+    ndvi = torch.from_numpy(np.clip(rs.standard_normal((B, 1, H, W)), -3, 3).astype(np.float32))
+    lst_up = torch.nn.functional.interpolate(lst, scale_factor=4, mode="bicubic", align_corners=False)
+    sr_o, (ds_o, pl_o, loss_o), _ = O.forward_backward(copy.deepcopy(sd), lst, lst_up, ndvi, MEAN, STD, 0.5, -0.25, "sr2")
+    sr, (ds, pl, loss), g, masks, m = _hip_forward_backward(sifsr, sd, lst, lst_up, ndvi, 0.5, -0.25, "sr2")
+    assert rel_err(sr, sr_o) < TOL
+    for got, ref in ((ds, ds_o), (pl, pl_o), (loss, loss_o)):
+        assert abs(got - float(ref)) < TOL * abs(float(ref))
+    sd64 = {k: (v.double() if v.dtype == torch.float32 else v.clone()) for k, v in sd.items()}
+    O.RELU_MASKS = masks
+    try:
+        _, _, g64m = O.forward_backward(sd64, lst.double(), lst_up.double(), ndvi.double(), MEAN, STD, 0.5, -0.25, "sr2")
+    finally:
+        O.RELU_MASKS = None
+    for n in g:
+        assert rel_err(g[n], g64m[n]) < TOL, (n, rel_err(g[n], g64m[n]))
+    # eval forward on the same shape
+    x = torch.cat((lst_up, ndvi), 1)
+    y_ref = O.modelb2_forward(copy.deepcopy(sd), x, training=False)
+    with torch.inference_mode():
+        y = make_model(sifsr, sd).eval()(x.cuda())
+    assert rel_err(y, y_ref) < TOL
