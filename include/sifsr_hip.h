@@ -140,6 +140,26 @@ SIFSR_API int sifsr_adam_flat(float* params, const float* grads, float* exp_avg,
                               float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                               void* stream);
 
+/* ---- the step before the path and the metrics after it --------------------
+ * sifsr_tiles_prepare: per tile, what dataset.py:134-142 / predict.py:84-100 do on the host: z-score of the
+ * win x win LST tile, bicubic x4 (us.upsampling = cv2.resize INTER_CUBIC, utils.py:163-180; A = -0.75, half-pixel
+ * centres, edge clamp), NDVI optional clip to [-1,1] + z-score, torch.cat((lst_up, ndvi), 1) -> x (T,2,4win,4win).
+ *   granule = 1: lst is ONE raster (lst_h, lst_w), ndvi (4 lst_h, 4 lst_w); tiles (ty,tx) at (win*ty, win*tx)
+ *   granule = 0: lst (T,1,win,win), ndvi (T,1,4win,4win) with T = tiles_y*tiles_x (lst_h, lst_w ignored)
+ * Pass mean 0 / std 1 for already normalised inputs.  win % 4 == 0, win <= 64.
+ * sifsr_tiles_paste: predict.py:101-103, out[4win*ty + Y][4win*tx + X] = sr*std_lst + mean_lst, out (4 lst_h, 4 lst_w). */
+SIFSR_API int sifsr_tiles_prepare(const float* lst, const float* ndvi, float* x, int tiles_y, int tiles_x, int win, int lst_h,
+                                  int lst_w, int granule, float mean_lst, float std_lst, float mean_ndvi, float std_ndvi,
+                                  int clip_ndvi, void* stream);
+SIFSR_API int sifsr_tiles_paste(const float* sr, float* out, int tiles_y, int tiles_x, int win, int lst_w, float mean_lst,
+                                float std_lst, void* stream);
+/* us.psnr_skimage / us.ssim_skimage (utils.py:548-578) of (B,1,H,W) batches: out2[0] = mean_i PSNR_i,
+ * out2[1] = mean_i SSIM_i with scikit-image 0.22 defaults (7x7 uniform window, sample covariance, K1 0.01, K2 0.03)
+ * and data_range = max - min of the whole TARGET batch, as the reference passes it. */
+SIFSR_API size_t sifsr_psnr_ssim_scratch_bytes(int B, int H, int W);
+SIFSR_API int sifsr_psnr_ssim(const float* pred, const float* targ, int B, int H, int W, void* scratch, size_t scratch_bytes,
+                              float* out2, void* stream);
+
 /* ---- measurement hook (bench.py roofline) ------------------------------------------------------
  * Time ONE kernel of the model schedule with HIP events on its launch stream, inside normal steps:
  * layer = row of sifsr_layer_table, phase 1 = forward conv, 2 = dgrad, 3 = wgrad; layer < 0 disables.

@@ -8,6 +8,8 @@ Drop-in surface (SURVEY.md §8 b):
   optim.FlatAdam                      <- torch.optim.Adam, train_model_B_gradFTM.py:453
   dataset.ModisDatasetB               <- reference dataset.py:29 (synthetic drop-in, same __getitem__)
   train.train_step / predict.predict_tiles  <- train_model_B_gradFTM.py:86-121 / predict.py:84-103
+  pipeline.prepare_tiles / granule_to_tiles / tiles_to_granule, predict.predict_granule  <- dataset.py:134-142, predict.py:84-103
+  metrics.psnr_skimage / ssim_skimage  <- utils.py:548-578 (on device)
 
 The directory name is the repository's mandated package name (it contains '-', so it is imported
 through ``importlib`` or the ``sifsr`` alias: ``import sifsr`` at the repo root loads this package
@@ -16,7 +18,7 @@ and registers ``sifsr`` / ``sifsr.<submodule>`` as aliases of the same module ob
 import importlib
 import sys
 
-_SUBMODULES = ("_lib", "model", "sif_ops", "optim", "dataset", "distributed", "train", "predict")
+_SUBMODULES = ("_lib", "model", "sif_ops", "optim", "dataset", "distributed", "train", "pipeline", "metrics", "predict")
 for _m in _SUBMODULES:
     importlib.import_module(__name__ + "." + _m)
 

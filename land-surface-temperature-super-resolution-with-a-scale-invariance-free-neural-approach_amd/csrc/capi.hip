@@ -226,3 +226,33 @@ int sifsr_adam_flat(float* params, const float* grads, float* exp_avg, float* ex
 
 int sifsr_profile_select(int layer, int phase) { return sifsr_engine_profile_select(layer, phase); }
 int sifsr_profile_read(float* total_ms, int* count) { return sifsr_engine_profile_read(total_ms, count); }
+
+// ---- input pipeline / metrics ----
+int sifsr_tiles_prepare(const float* lst, const float* ndvi, float* x, int tiles_y, int tiles_x, int win, int lst_h, int lst_w,
+                        int granule, float mean_lst, float std_lst, float mean_ndvi, float std_ndvi, int clip_ndvi,
+                        void* stream) {
+  if (!lst || !ndvi || !x || tiles_y < 1 || tiles_x < 1) return SIFSR_ERR_ARG;
+  const int hr = 4 * win;
+  if (granule) {
+    // tiles cut out of one raster: LST (lst_h, lst_w) row-major, NDVI (4 lst_h, 4 lst_w)
+    if (tiles_y * win > lst_h || tiles_x * win > lst_w) return SIFSR_ERR_SHAPE;
+    return launch_tiles_prepare(lst, ndvi, x, tiles_y * tiles_x, tiles_x, win, (long long)win * lst_w, win, lst_w,
+                                (long long)hr * 4 * lst_w, hr, 4 * lst_w, mean_lst, std_lst, mean_ndvi, std_ndvi, clip_ndvi,
+                                S(stream));
+  }
+  // a batch of separate tiles: lst (T,1,win,win), ndvi (T,1,hr,hr)
+  return launch_tiles_prepare(lst, ndvi, x, tiles_y * tiles_x, 1, win, (long long)win * win, 0, win, (long long)hr * hr, 0, hr,
+                              mean_lst, std_lst, mean_ndvi, std_ndvi, clip_ndvi, S(stream));
+}
+int sifsr_tiles_paste(const float* sr, float* out, int tiles_y, int tiles_x, int win, int lst_w, float mean_lst, float std_lst,
+                      void* stream) {
+  if (!sr || !out || tiles_x * win > lst_w) return SIFSR_ERR_ARG;
+  return launch_tiles_paste(sr, out, tiles_y * tiles_x, tiles_x, 4 * win, (long long)4 * lst_w, mean_lst, std_lst, S(stream));
+}
+size_t sifsr_psnr_ssim_scratch_bytes(int B, int H, int W) { return psnr_ssim_scratch_bytes(B, H, W); }
+int sifsr_psnr_ssim(const float* pred, const float* targ, int B, int H, int W, void* scratch, size_t scratch_bytes, float* out2,
+                    void* stream) {
+  if (!pred || !targ || !scratch || !out2) return SIFSR_ERR_ARG;
+  if (scratch_bytes < psnr_ssim_scratch_bytes(B, H, W)) return SIFSR_ERR_WORKSPACE;
+  return launch_psnr_ssim(pred, targ, B, H, W, scratch, out2, S(stream));
+}

@@ -49,3 +49,12 @@ int launch_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, h
 // ---- adam.hip ----
 int launch_adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, float grad_scale, hipStream_t s);
+
+// ---- pipeline.hip ---- (input pipeline before the model, metrics after it: SURVEY.md §8 f2 / f1)
+int launch_tiles_prepare(const float* lst, const float* ndvi, float* x, int T, int tiles_x, int win, long long lst_step_y,
+                         long long lst_step_x, int lst_row, long long ndvi_step_y, long long ndvi_step_x, int ndvi_row,
+                         float mean_lst, float std_lst, float mean_ndvi, float std_ndvi, int clip_ndvi, hipStream_t s);
+int launch_tiles_paste(const float* sr, float* out, int T, int tiles_x, int hr, long long out_row, float mean, float std,
+                       hipStream_t s);
+size_t psnr_ssim_scratch_bytes(int B, int H, int W);
+int launch_psnr_ssim(const float* pred, const float* targ, int B, int H, int W, void* scratch, float* out2, hipStream_t s);

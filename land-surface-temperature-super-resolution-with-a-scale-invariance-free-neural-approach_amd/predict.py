@@ -21,6 +21,22 @@ def predict_tiles(model, lst_up, ndvi, stats, batch=256):
     return out
 
 
+@torch.inference_mode()
+def predict_granule(model, lst_g, ndvi_g, stats, window=64, batch=256):
+    """The whole block loop of predict.py:84-103 on the device: raw LST raster (h,w) [K] + raw NDVI raster
+    (4h,4w) -> super-resolved LST raster (4h,4w) [K].  Tiles are cut, normalised, bicubic-upsampled and
+    concatenated by one kernel, pushed through the network in batches, de-normalised and pasted by another;
+    pixels of ragged edge tiles stay 0, as in the reference (``LST_SR = np.zeros(...)``)."""
+    from . import pipeline
+    model.eval()
+    x, tiles = pipeline.granule_to_tiles(lst_g, ndvi_g, stats, window=window, clip_ndvi=True)
+    sr = torch.empty((x.shape[0], 1, 4 * window, 4 * window), dtype=torch.float32, device=x.device)
+    for i in range(0, x.shape[0], batch):
+        sr[i:i + batch] = model(x[i:i + batch])
+    out = torch.zeros((4 * lst_g.shape[0], 4 * lst_g.shape[1]), dtype=torch.float32, device=x.device)
+    return pipeline.tiles_to_granule(sr, out, tiles, window, stats)
+
+
 def tile_granule(lst_norm, ndvi_norm, window=64):
     """Cut a normalised LST raster (h,w) and its 4x NDVI raster into the non-overlapping tiles of
     predict.py:84-95 (ragged edge tiles are skipped, as in the reference).  Returns

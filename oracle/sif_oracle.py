@@ -353,3 +353,67 @@ def digest(t: torch.Tensor, nsamples: int = 64):
     idx = torch.linspace(0, n - 1, min(nsamples, n)).long()
     return {"shape": list(t.shape), "sum": float(d.sum()), "abs_sum": float(d.abs().sum()),
             "l2": float(d.norm()), "samples": [float(v) for v in d[idx]]}
+
+
+# ----------------------------------------------------------------------------------------------
+# Input pipeline (dataset.py:134-142, predict.py:84-103) and train-time metrics (utils.py:548-578)
+# ----------------------------------------------------------------------------------------------
+def prepare_tiles(lst, ndvi, stats=None, clip_ndvi=False):
+    """dataset.py:134-142 / predict.py:88-99 per tile: z-score, us.upsampling (cv2.resize INTER_CUBIC x4,
+    utils.py:163-180 -- restated with F.interpolate bicubic, align_corners=False: same A = -0.75 kernel,
+    half-pixel centres, edge clamp; OpenCV absent => parity with cv2 unpinned), NDVI clip + z-score, cat."""
+    st = stats or {"mean_lst": 0.0, "std_lst": 1.0, "mean_ndvi": 0.0, "std_ndvi": 1.0}
+    l = (lst - st["mean_lst"]) / st["std_lst"]
+    lst_up = F.interpolate(l, scale_factor=4, mode="bicubic", align_corners=False)
+    n = ndvi.clamp(-1, 1) if clip_ndvi else ndvi
+    n = (n - st["mean_ndvi"]) / st["std_ndvi"]
+    return torch.cat((lst_up, n), dim=1)
+
+
+def predict_granule(sd, lst_g, ndvi_g, stats, window=64):
+    """predict.py:84-103: block loop over the full 64x64 LST tiles of a granule, batch 1 per tile."""
+    out = torch.zeros((ndvi_g.shape[0], ndvi_g.shape[1]), dtype=lst_g.dtype)
+    for i in range(0, lst_g.shape[0], window):
+        for j in range(0, lst_g.shape[1], window):
+            lb = lst_g[i:i + window, j:j + window]
+            if lb.shape != (window, window):
+                continue
+            nb = ndvi_g[4 * i:4 * (i + window), 4 * j:4 * (j + window)]
+            x = prepare_tiles(lb[None, None], nb[None, None], stats, clip_ndvi=True)
+            y = modelb2_forward(sd, x, training=False)
+            out[4 * i:4 * (i + window), 4 * j:4 * (j + window)] = y[0, 0] * stats["std_lst"] + stats["mean_lst"]
+    return out
+
+
+def psnr_skimage(predictions, targets):
+    """utils.py:548-552 with skimage.metrics.peak_signal_noise_ratio (scikit-image 0.22, not installed here --
+    restated: float32 difference, mean of squares accumulated in float64, 10*log10(range^2 / mse))."""
+    p, t = np.asarray(predictions, dtype=np.float32), np.asarray(targets, dtype=np.float32)
+    rng = float(t.max() - t.min())
+    vals = []
+    for i in range(t.shape[0]):
+        mse = np.mean((t[i, 0] - p[i, 0]) ** 2, dtype=np.float64)
+        vals.append(10 * np.log10(rng ** 2 / mse))
+    return float(np.mean(vals))
+
+
+def ssim_skimage(predictions, targets):
+    """utils.py:554-578 with skimage.metrics.structural_similarity defaults (scikit-image 0.22, restated):
+    win 7, scipy.ndimage.uniform_filter (float64 accumulation, float32 result for float32 images), sample
+    covariance NP/(NP-1), K1 = 0.01, K2 = 0.03, mean over the map cropped by (win-1)//2."""
+    from scipy.ndimage import uniform_filter
+    p, t = np.asarray(predictions, dtype=np.float32), np.asarray(targets, dtype=np.float32)
+    R = np.float32(t.max() - t.min())
+    C1, C2 = (np.float32(0.01) * R) ** 2, (np.float32(0.03) * R) ** 2
+    cov_norm = np.float32(49.0 / 48.0)
+    vals = []
+    for i in range(t.shape[0]):
+        im1, im2 = t[i, 0], p[i, 0]
+        ux, uy = uniform_filter(im1, size=7), uniform_filter(im2, size=7)
+        uxx, uyy, uxy = uniform_filter(im1 * im1, size=7), uniform_filter(im2 * im2, size=7), uniform_filter(im1 * im2, size=7)
+        vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+        A1, A2 = 2 * ux * uy + C1, 2 * vxy + C2
+        B1, B2 = ux ** 2 + uy ** 2 + C1, vx + vy + C2
+        S = (A1 * A2) / (B1 * B2)
+        vals.append(S[3:-3, 3:-3].mean(dtype=np.float64))
+    return float(np.mean(vals))
