@@ -160,6 +160,14 @@ SIFSR_API size_t sifsr_psnr_ssim_scratch_bytes(int B, int H, int W);
 SIFSR_API int sifsr_psnr_ssim(const float* pred, const float* targ, int B, int H, int W, void* scratch, size_t scratch_bytes,
                               float* out2, void* stream);
 
+/* Fourier-domain evaluation of (B,H,W) images, H and W powers of two (4..2048):
+ *   mag      (optional, (B,H,W))  = np.fft.fftshift(np.abs(sp.fft.fft2(img)))            compare_methods.py:312-324
+ *   spectrum (optional, (B,nr+1)) = us.compute_2D_attenuation_spectra(mag), nr = min(H/2, W/2) - 1   utils.py:598-636
+ * hand-written radix-2 FFT in LDS, float64 throughout (ring means in float64, stored as float32 dB values). */
+SIFSR_API size_t sifsr_fft2_attenuation_scratch_bytes(int B, int H, int W);
+SIFSR_API int sifsr_fft2_attenuation(const float* img, int B, int H, int W, void* scratch, size_t scratch_bytes, float* mag,
+                                     float* spectrum, void* stream);
+
 /* ---- measurement hook (bench.py roofline) ------------------------------------------------------
  * Time ONE kernel of the model schedule with HIP events on its launch stream, inside normal steps:
  * layer = row of sifsr_layer_table, phase 1 = forward conv, 2 = dgrad, 3 = wgrad; layer < 0 disables.

@@ -10,6 +10,7 @@ Drop-in surface (SURVEY.md §8 b):
   train.train_step / predict.predict_tiles  <- train_model_B_gradFTM.py:86-121 / predict.py:84-103
   pipeline.prepare_tiles / granule_to_tiles / tiles_to_granule, predict.predict_granule  <- dataset.py:134-142, predict.py:84-103
   metrics.psnr_skimage / ssim_skimage  <- utils.py:548-578 (on device)
+  fourier.fft2_magnitude / attenuation_spectra / get_FRR / get_FRO / get_FRU  <- compare_methods.py:312-324, utils.py:598-662
 
 The directory name is the repository's mandated package name (it contains '-', so it is imported
 through ``importlib`` or the ``sifsr`` alias: ``import sifsr`` at the repo root loads this package
@@ -18,7 +19,7 @@ and registers ``sifsr`` / ``sifsr.<submodule>`` as aliases of the same module ob
 import importlib
 import sys
 
-_SUBMODULES = ("_lib", "model", "sif_ops", "optim", "dataset", "distributed", "train", "pipeline", "metrics", "predict")
+_SUBMODULES = ("_lib", "model", "sif_ops", "optim", "dataset", "distributed", "train", "pipeline", "metrics", "fourier", "predict")
 for _m in _SUBMODULES:
     importlib.import_module(__name__ + "." + _m)
 

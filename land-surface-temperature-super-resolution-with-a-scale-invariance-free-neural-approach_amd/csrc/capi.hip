@@ -256,3 +256,12 @@ int sifsr_psnr_ssim(const float* pred, const float* targ, int B, int H, int W, v
   if (scratch_bytes < psnr_ssim_scratch_bytes(B, H, W)) return SIFSR_ERR_WORKSPACE;
   return launch_psnr_ssim(pred, targ, B, H, W, scratch, out2, S(stream));
 }
+
+// ---- Fourier-domain evaluation ----
+size_t sifsr_fft2_attenuation_scratch_bytes(int B, int H, int W) { return fourier_scratch_bytes(B, H, W); }
+int sifsr_fft2_attenuation(const float* img, int B, int H, int W, void* scratch, size_t scratch_bytes, float* mag,
+                           float* spectrum, void* stream) {
+  if (!img || !scratch || (!mag && !spectrum)) return SIFSR_ERR_ARG;
+  if (scratch_bytes < fourier_scratch_bytes(B, H, W)) return SIFSR_ERR_WORKSPACE;
+  return launch_fft2_attenuation(img, B, H, W, scratch, mag, spectrum, S(stream));
+}

@@ -58,3 +58,7 @@ int launch_tiles_paste(const float* sr, float* out, int T, int tiles_x, int hr, 
                        hipStream_t s);
 size_t psnr_ssim_scratch_bytes(int B, int H, int W);
 int launch_psnr_ssim(const float* pred, const float* targ, int B, int H, int W, void* scratch, float* out2, hipStream_t s);
+
+// ---- fourier.hip ---- (Fourier-domain evaluation)
+size_t fourier_scratch_bytes(int B, int H, int W);
+int launch_fft2_attenuation(const float* img, int B, int H, int W, void* scratch, float* mag, float* spectrum, hipStream_t s);

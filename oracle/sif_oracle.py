@@ -417,3 +417,37 @@ def ssim_skimage(predictions, targets):
         S = (A1 * A2) / (B1 * B2)
         vals.append(S[3:-3, 3:-3].mean(dtype=np.float64))
     return float(np.mean(vals))
+
+
+# ----------------------------------------------------------------------------------------------
+# Fourier-domain evaluation (compare_methods.py:312-324, utils.py:598-662)
+# ----------------------------------------------------------------------------------------------
+def fft2_magnitude_shifted(img):
+    """compare_methods.py:312: np.fft.fftshift(np.abs(sp.fft.fft2(img))) -- float64 here."""
+    return np.fft.fftshift(np.abs(np.fft.fft2(np.asarray(img, dtype=np.float64))))
+
+
+def attenuation_spectrum(im):
+    """utils.py:598-636 on the shifted magnitude ``im``: ring r = {r^2 < d^2 <= (r+1)^2} around
+    (H//2, W//2), r < min(H//2, W//2) - 1; [f0/f0 = 1, 10*(log10(mean ring) - log10(f0)), ...]."""
+    im = np.asarray(im, dtype=np.float64)
+    c0, c1 = im.shape[0] // 2, im.shape[1] // 2
+    ii, jj = np.meshgrid(np.arange(im.shape[0]), np.arange(im.shape[1]), indexing="ij")
+    d2 = (ii - c0) ** 2 + (jj - c1) ** 2
+    f0 = im[c0, c1]
+    out = [f0 / f0]
+    for r in range(0, min(c0 - 1, c1 - 1)):
+        mask = (d2 <= (r + 1) ** 2) & ~(d2 <= r ** 2)
+        out.append(10 * (np.log10(im[mask].sum() / mask.sum()) - np.log10(f0)))
+    return out
+
+
+def frr_fro_fru(pb, rb, xb):
+    """utils.py:638-662 (pb prediction, rb ground truth, xb bicubic spectra) -> (FRR, FRO, FRU)."""
+    pb, rb, xb = (np.asarray(v, dtype=np.float64) for v in (pb, rb, xb))
+    pfr = np.maximum(rb - xb, 0).sum()
+    t3 = np.minimum(rb, xb)
+    afr = (np.maximum(np.minimum(pb, rb), np.minimum(xb, rb)) - t3).sum()
+    fro = (rb - np.maximum(pb, rb)).sum() / rb.sum()
+    fru = (xb - np.minimum(pb, xb)).sum() / xb.sum()
+    return afr / pfr, fro, fru
