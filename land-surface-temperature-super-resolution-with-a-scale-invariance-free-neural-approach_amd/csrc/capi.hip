@@ -102,7 +102,7 @@ int sifsr_conv3x3_wgrad(const float* src0, int C0, const float* scale0, const fl
   a.src[1] = mk_src(src1, C1, scale1, shift1);
   a.dy = dy; a.slabs = scratch; a.B = B; a.H = H; a.W = W;
   a.NQ = a.src[0].nq + a.src[1].nq;
-  a.ntiles = B * (H / 8) * (W / 16);
+  a.ntiles = B * ((H + 7) / 8) * ((W + 15) / 16);
   const int cin = 16 * a.NQ;
   if (nblk > a.ntiles) nblk = a.ntiles;
   int rc = launch_conv3x3_wgrad(a, cin, cout, nblk, S(stream));

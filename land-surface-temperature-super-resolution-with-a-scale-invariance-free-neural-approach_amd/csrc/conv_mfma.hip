@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
   const bool producer = wave8 >= 4;
   const int wave = wave8 & 3;
   const int H = a.H, W = a.W;
-  const int tiles_x = W / 16, tiles_y = H / 16;
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;   // the last tile row / column may be partial
   const int NQ = a.NQ;
   const unsigned npix = (unsigned)a.B * (unsigned)H * (unsigned)W;
 
@@ -257,6 +257,10 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
     int cb, txi, tyi;
     tile_pos(t, cb, txi, tyi);
     const unsigned tile_pix = (unsigned)((cb * H + tyi * 16 + g0) * W + txi * 16);
+    // partial tiles (H or W not a multiple of 16 at this level): columns past W get an out-of-range offset (the
+    // store is dropped, the addend reads 0) and stay out of the statistics; rows past H are skipped.
+    const bool colok = txi * 16 + px < W;
+    const int rows_ok = H - (tyi * 16 + g0);
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
       const int nb = nb0 + 4 * c;
@@ -264,20 +268,22 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
       const int dC = d0 ? a.dst[0].C : a.dst[1].C;
       const __amdgpu_buffer_rsrc_t rd = d0 ? rd0 : rd1;
       const unsigned chb = (unsigned)((d0 ? a.dst[0].coff + 16 * nb : a.dst[1].coff + 16 * (nb - a.dst_split)) + 4 * kq) * 4u;
-      const unsigned vo = (unsigned)px * (unsigned)dC * 4u + chb;
-      const unsigned va = (unsigned)px * (unsigned)a.addC * 4u + (unsigned)(16 * nb + 4 * kq) * 4u;
+      const unsigned vo = colok ? (unsigned)px * (unsigned)dC * 4u + chb : OOB;
+      const unsigned va = colok ? (unsigned)px * (unsigned)a.addC * 4u + (unsigned)(16 * nb + 4 * kq) * 4u : OOB;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const unsigned rowpix = tile_pix + (unsigned)(g * W);
         f32x4 v = acc[c][g];
+        acc[c][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (g >= rows_ok) continue;
         if (a.addend != nullptr) {
           const float4 ad = bload4(rad, va, rowpix * (unsigned)a.addC * 4u);
           v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
         }
         bstore4(rd, vo, rowpix * (unsigned)dC * 4u, make_float4(v[0], v[1], v[2], v[3]));
+        if (!colok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[c][r] += v[r]; s2[c][r] = fmaf(v[r], v[r], s2[c][r]); }
-        acc[c][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
     if (!more) break;
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int NBI = Cin / 16, NQ = Cout / 16;
-  const int seg_tb = W / 16, seg_lr = (H - 2 + 15) / 16;
+  const int seg_tb = (W + 15) / 16, seg_lr = (H - 2 + 15) / 16;
   const int per_img = (2 * seg_tb + 2 * seg_lr) * NBI;
   if (wave_g >= B * per_img) return;                       // wave-uniform
   const int b = wave_g / per_img;
@@ -404,13 +410,14 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
   bool valid = true;
   if (side < 2) {
     qy = side == 0 ? 0 : H - 1; qx = seg * 16 + px;
+    valid = qx < W;                                         // partial last segment when W is not a multiple of 16
     const int ty = side == 0 ? -1 : 1;
     const int yin = side == 0 ? 1 : H - 2;                  // the row next to the border row
     for (int q = 0; q < NQ; ++q) {
 #pragma unroll
       for (int tx = -1; tx <= 1; ++tx) {
         const int sx = qx - tx;
-        mac((ty + 1) * 3 + (tx + 1), q, (sx >= 0 && sx < W) ? row(qy, sx, q) : z4);
+        mac((ty + 1) * 3 + (tx + 1), q, (valid && sx >= 0 && sx < W) ? row(qy, sx, q) : z4);
       }
       if (seg == 0) {                                       // left corner lane (qx == 0): taps (0,-1) and (ty,-1)
         const bool c = qx == 0;
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
 // Number of persistent workgroups (== rows of stat_partials written) for a B x H x W conv with cout outputs:
 // at most 256 CUs x the residency the kernel variant reaches, and an even split of the tiles.
 int conv3x3_grid_blocks(int B, int H, int W, int cout) {
-  const int ntiles = B * (H / 16) * (W / 16);
+  const int ntiles = B * ((H + 15) / 16) * ((W + 15) / 16);
   const int per_cu = cout >= 64 ? 1 : 2;   // residency of the kernel variants (VGPR-limited)
   static const int dbg_grid = getenv("SIFSR_DBG_CONV_GRID") ? atoi(getenv("SIFSR_DBG_CONV_GRID")) : 0;   // tuning knob
   const int gmax = dbg_grid > 0 ? dbg_grid : 256 * per_cu;
@@ -464,9 +471,9 @@ int conv3x3_grid_blocks(int B, int H, int W, int cout) {
 }
 
 int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s) {
-  if (a.H % 16 || a.W % 16 || cout % 16 || a.NQ < 1 || a.src[0].nq + a.src[1].nq != a.NQ) return SIFSR_ERR_SHAPE;
+  if (a.H < 1 || a.W < 1 || cout % 16 || a.NQ < 1 || a.src[0].nq + a.src[1].nq != a.NQ) return SIFSR_ERR_SHAPE;
   if (!a.src[0].ptr || !a.dst[0].ptr || !a.wpack) return SIFSR_ERR_ARG;
-  const int ntiles = a.B * (a.H / 16) * (a.W / 16);
+  const int ntiles = a.B * ((a.H + 15) / 16) * ((a.W + 15) / 16);
   const dim3 grid(conv3x3_grid_blocks(a.B, a.H, a.W, cout)), block(512);
   const int nb = cout / 16;
   // 32-bit byte offsets (buffer addressing): every tensor must stay below 4 GiB; channel counts powers of two
@@ -478,7 +485,7 @@ int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s
   cmax = cmax > a.dst[1].C ? cmax : a.dst[1].C;
   if (npix * cmax * 4 >= ((size_t)1 << 32) - 4096) return SIFSR_ERR_SHAPE;
   if (!pow2(a.src[0].C) || (a.src[1].ptr && !pow2(a.src[1].C))) return SIFSR_ERR_SHAPE;
-  const int tx_ = a.W / 16, ty_ = a.H / 16;
+  const int tx_ = (a.W + 15) / 16, ty_ = (a.H + 15) / 16;
   const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
 #define SIFSR_CONV_CASE(NBV)                                                                              \
   case NBV:                                                                                               \
@@ -527,8 +534,8 @@ int launch_pack_weights_one(const float* w, int cin, int cout, float* wfwd, floa
 
 int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, int Cin, float* g0, int C0,
                             int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s) {
-  if (H < 3 || W % 16 || Cin % 16 || Cout % 16) return SIFSR_ERR_SHAPE;
-  const int waves = B * (2 * (W / 16) + 2 * ((H - 2 + 15) / 16)) * (Cin / 16);
+  if (H < 3 || W < 2 || Cin % 16 || Cout % 16) return SIFSR_ERR_SHAPE;
+  const int waves = B * (2 * ((W + 15) / 16) + 2 * ((H - 2 + 15) / 16)) * (Cin / 16);
   hipLaunchKernelGGL(dgrad_border_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, dy, Cout, wdg_layer, Cin, g0, C0,
                      split_ch, g1, C1, B, H, W);
   SIFSR_LAUNCH_CHECK();

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wo = wave % WO, wi = (wave / WO) % WI, wp = wave / (WO * WI);
   const int H = a.H, W = a.W;
-  const int tiles_x = W / 16, tiles_y = H / WT_ROWS;
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + WT_ROWS - 1) / WT_ROWS;   // last row / column of tiles may be partial
   const int q0 = blockIdx.y * NBI;   // first 16-channel block of my cin chunk
   constexpr int Cout = NBO * 16;
   const unsigned npix = (unsigned)a.B * (unsigned)H * (unsigned)W;
@@ -97,8 +97,19 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
     else { txi = tile % tiles_x; const int r = tile / tiles_x; tyi = r % tiles_y; b = r / tiles_y; }
     const int x0 = txi * 16, y0 = tyi * WT_ROWS;
     const unsigned base = (unsigned)((b * H + y0) * W + x0);
+    if (x0 + 16 <= W && y0 + WT_ROWS <= H) {
 #pragma unroll
-    for (int i = 0; i < NIO; ++i) pdy[i] = wg_bload4(rdy, vo_dy[i], base * (unsigned)(Cout * 4));
+      for (int i = 0; i < NIO; ++i) pdy[i] = wg_bload4(rdy, vo_dy[i], base * (unsigned)(Cout * 4));
+    } else {
+      // partial tile: dy of the pixels outside the image must read as 0 (they contribute nothing to dW):
+      // a per-lane offset beyond the descriptor's range makes the buffer load return 0
+#pragma unroll
+      for (int i = 0; i < NIO; ++i) {
+        const int p = po0 + i * PPO;
+        const bool in = y0 + (p >> 4) < H && x0 + (p & 15) < W;
+        pdy[i] = wg_bload4(rdy, in ? vo_dy[i] : 0xFFFFFF00u, base * (unsigned)(Cout * 4));
+      }
+    }
     const bool interior = txi > 0 && tyi > 0 && txi + 1 < tiles_x && tyi + 1 < tiles_y;
     const unsigned chb = (unsigned)(ch0 + 4 * c4i) * 4u;
     if (interior) {
@@ -296,7 +307,7 @@ template <int NBO, int NBI>
 int launch_wgrad_t(const WgradArgs& a, int chunks, int nblk, hipStream_t s) {
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
   auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
-  const int tx_ = a.W / 16, ty_ = a.H / WT_ROWS;
+  const int tx_ = (a.W + 15) / 16, ty_ = (a.H + WT_ROWS - 1) / WT_ROWS;
   const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
   hipLaunchKernelGGL((conv3x3_wgrad_kernel<NBO, NBI>), dim3(nblk, chunks), dim3(256), 0, s, a, lgx, lgy);
   SIFSR_LAUNCH_CHECK();
@@ -317,7 +328,8 @@ int wgrad_nbi_chunk(const WgradArgs& a, int cin) {
 }
 
 int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s) {
-  if (a.H % WT_ROWS || a.W % 16 || cin % 16 || cout % 16 || nblk < 1) return SIFSR_ERR_SHAPE;
+  if (a.H < 1 || a.W < 1 || cin % 16 || cout % 16 || nblk < 1) return SIFSR_ERR_SHAPE;
+  if (a.ntiles != a.B * ((a.H + WT_ROWS - 1) / WT_ROWS) * ((a.W + 15) / 16)) return SIFSR_ERR_ARG;
   {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     const size_t npix = (size_t)a.B * a.H * a.W;

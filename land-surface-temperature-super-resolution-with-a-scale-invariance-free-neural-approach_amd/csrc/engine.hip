@@ -62,7 +62,9 @@ static int wgrad_blocks(int cin, int cout, int chunks, int ntiles) {
 }
 
 int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
-  if (B < 1 || H < 128 || W < 128 || H % 128 || W % 128) return SIFSR_ERR_SHAPE;
+  // three 2x poolings + exact x2 upsamplings back: H, W multiples of 8 (model.py:597-603); the thin first / last
+  // convs work on whole 16x16 tiles, and the deepest level must still have a 3x3 neighbourhood and >= 2 rows
+  if (B < 1 || H < 32 || W < 32 || H % 16 || W % 16) return SIFSR_ERR_SHAPE;
   const NetTable& nt = sifsr_net();
   WsLayout& w = *o;
   size_t off = 0;
@@ -100,7 +102,8 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
     w.slabs = take(1024 * 288);   // edge-layer partials
     w.slab_l[0] = 0;
     for (int l = 1; l < SIFSR_NUM_BN_LAYERS; ++l) {
-      const int ntiles = (int)(N[nt.L[l].level] / 128);
+      const int lvh = H >> nt.L[l].level, lvw = W >> nt.L[l].level;
+      const int ntiles = B * ((lvh + 7) / 8) * ((lvw + 15) / 16);
       // upper bound over chunkings (x-dim blocks * chunks <= blocks at one chunk)
       w.slab_l[l] = take((size_t)wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles) * 9 * nt.L[l].cin * nt.L[l].cout);
     }
@@ -213,7 +216,7 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
   a.dy = dy; a.slabs = c.f(c.lay.slab_l[l]);
   a.B = c.B; a.H = c.lvH(L.level); a.W = c.lvW(L.level);
   a.NQ = L.cin / 16;
-  a.ntiles = c.B * (a.H / 8) * (a.W / 16);
+  a.ntiles = c.B * ((a.H + 7) / 8) * ((a.W + 15) / 16);
   const int nbi = wgrad_nbi_chunk(a, L.cin);
   const int nblk = wgrad_blocks(L.cin, L.cout, L.cin / (16 * nbi), a.ntiles);
   {

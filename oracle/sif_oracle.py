@@ -281,7 +281,14 @@ def sr1_loss(sr, lst, ndvi, mean, std, alpha, gamma):
     return ds, pl, alpha * ds + (1 - alpha) * pl
 
 
-LOSSES = {"sr2": sr2_loss, "sr1": sr1_loss}
+def si_loss(sr, lst, ndvi, mean, std, alpha, gamma):
+    """train_model_B_scale_invariance.py:98: plain Huber against a same-resolution target (passed as ``ndvi``
+    here, so the three-tensor batch signature of the other two steps is kept) -> (loss, 0, loss)."""
+    ds = huber(sr, ndvi)
+    return ds, torch.zeros((), dtype=sr.dtype), ds
+
+
+LOSSES = {"sr2": sr2_loss, "sr1": sr1_loss, "si": si_loss}
 
 
 # ----------------------------------------------------------------------------------------------

@@ -77,7 +77,11 @@ def _hip_forward_backward(sifsr, sd, lst, lst_up, ndvi, alpha, gamma, kind):
     S = torch.cuda.current_stream().cuda_stream
     L.call("sifsr_model_forward", x, sr, fp, fr, fn, ws, wsb, B, H, W, 1, 0.1, 1e-5, S)
     srr = sr.clone().requires_grad_(True)
-    ds, pl, loss = sifsr.sif_loss(kind, srr, lst.cuda(), ndvi.cuda(), MEAN, STD, alpha, gamma)
+    if kind == "si":      # scale-invariance baseline: plain Huber against a same-size target (oracle.si_loss)
+        loss = sifsr.huber_loss(srr, ndvi.cuda())
+        ds, pl = loss.detach(), torch.zeros(())
+    else:
+        ds, pl, loss = sifsr.sif_loss(kind, srr, lst.cuda(), ndvi.cuda(), MEAN, STD, alpha, gamma)
     (dsr,) = torch.autograd.grad(loss, srr)
     grads = torch.empty_like(fp)
     L.call("sifsr_model_backward", x, dsr.contiguous(), fp, grads, ws, wsb, B, H, W, S)
@@ -299,25 +303,30 @@ def test_graph_captured_inference(sifsr, golden):
     assert rel_err(out2, ref2) < TOL
 
 
-def test_non_square_patches(sifsr):
-    """128 x 384 patches: the tile grids are 8x24 / 4x12 / ... -- not powers of two, so every persistent kernel
-    takes its generic tile-index path and every level has border tiles on all four sides.  Forward, losses and
+@pytest.mark.parametrize("shape", [(2, 128, 384), (3, 64, 64), (2, 48, 80), (1, 32, 32)])
+def test_other_patch_sizes(sifsr, shape):
+    """128 x 384: tile grids 8x24 / 4x12 / ... (not powers of two: generic tile-index paths, borders on all sides).
+    64 x 64 (the scale-invariance baseline's patches), 48 x 80, 32 x 32: the deeper levels are smaller than / not
+    multiples of the 16x16 conv tiles, so the partial-tile paths of every conv kernel run.  Forward, losses and
     gradients (at the masks the HIP forward took) against the oracle."""
     rs = np.random.RandomState(5)
-    B, H, W = 2, 128, 384
+    B, H, W = shape
     sd = O.synthetic_state(23)
     lst = torch.from_numpy(rs.standard_normal((B, 1, H // 4, W // 4)).astype(np.float32))
     ndvi = torch.from_numpy(np.clip(rs.standard_normal((B, 1, H, W)), -3, 3).astype(np.float32))
     lst_up = torch.nn.functional.interpolate(lst, scale_factor=4, mode="bicubic", align_corners=False)
-    sr_o, (ds_o, pl_o, loss_o), _ = O.forward_backward(copy.deepcopy(sd), lst, lst_up, ndvi, MEAN, STD, 0.5, -0.25, "sr2")
-    sr, (ds, pl, loss), g, masks, m = _hip_forward_backward(sifsr, sd, lst, lst_up, ndvi, 0.5, -0.25, "sr2")
+    # the fused SIF loss kernels work on whole 32x32 tiles (>= 64): smaller / other sizes use the plain Huber of the
+    # scale-invariance baseline (train_model_B_scale_invariance.py:98), which is what trains on 64x64 patches
+    kind = "sr2" if (H % 32 == 0 and W % 32 == 0 and H >= 64 and W >= 64 and H != 64) else "si"
+    sr_o, (ds_o, pl_o, loss_o), _ = O.forward_backward(copy.deepcopy(sd), lst, lst_up, ndvi, MEAN, STD, 0.5, -0.25, kind)
+    sr, (ds, pl, loss), g, masks, m = _hip_forward_backward(sifsr, sd, lst, lst_up, ndvi, 0.5, -0.25, kind)
     assert rel_err(sr, sr_o) < TOL
     for got, ref in ((ds, ds_o), (pl, pl_o), (loss, loss_o)):
-        assert abs(got - float(ref)) < TOL * abs(float(ref))
+        assert abs(got - float(ref)) <= TOL * abs(float(ref))
     sd64 = {k: (v.double() if v.dtype == torch.float32 else v.clone()) for k, v in sd.items()}
     O.RELU_MASKS = masks
     try:
-        _, _, g64m = O.forward_backward(sd64, lst.double(), lst_up.double(), ndvi.double(), MEAN, STD, 0.5, -0.25, "sr2")
+        _, _, g64m = O.forward_backward(sd64, lst.double(), lst_up.double(), ndvi.double(), MEAN, STD, 0.5, -0.25, kind)
     finally:
         O.RELU_MASKS = None
     for n in g:

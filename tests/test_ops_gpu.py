@@ -57,6 +57,12 @@ CONV_CASES = [
     (16, 16, 16, 32, 32, 2, False, True),    # ub3
     (64, 0, 32, 16, 16, 2, True, False),
     (32, 0, 16, 32, 16, 1, True, False),
+    # partial tiles: H / W not multiples of 16 (deeper levels of 64x64 ... 48x80 patches)
+    (64, 0, 64, 8, 8, 3, True, False),
+    (64, 64, 64, 12, 20, 2, False, True),
+    (32, 0, 32, 24, 40, 2, True, False),
+    (16, 0, 32, 20, 36, 1, True, False),
+    (64, 0, 64, 4, 6, 2, True, False),
 ]
 
 
