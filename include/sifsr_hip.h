@@ -160,6 +160,10 @@ SIFSR_API size_t sifsr_psnr_ssim_scratch_bytes(int B, int H, int W);
 SIFSR_API int sifsr_psnr_ssim(const float* pred, const float* targ, int B, int H, int W, void* scratch, size_t scratch_bytes,
                               float* out2, void* stream);
 
+/* us.downsampling (utils.py:183-213), the 'norm-L4' decimation used by the scale-invariance baseline's dataset
+ * (dataset.py:258): out[b][i][j] = (mean over the 4x4 block of x^4)^(1/4); x (B,H,W), H and W multiples of 4. */
+SIFSR_API int sifsr_l4pool4(const float* x, float* out, int B, int H, int W, void* stream);
+
 /* Fourier-domain evaluation of (B,H,W) images, H and W powers of two (4..2048):
  *   mag      (optional, (B,H,W))  = np.fft.fftshift(np.abs(sp.fft.fft2(img)))            compare_methods.py:312-324
  *   spectrum (optional, (B,nr+1)) = us.compute_2D_attenuation_spectra(mag), nr = min(H/2, W/2) - 1   utils.py:598-636

@@ -265,3 +265,9 @@ int sifsr_fft2_attenuation(const float* img, int B, int H, int W, void* scratch,
   if (scratch_bytes < fourier_scratch_bytes(B, H, W)) return SIFSR_ERR_WORKSPACE;
   return launch_fft2_attenuation(img, B, H, W, scratch, mag, spectrum, S(stream));
 }
+
+// ---- scale-invariance baseline: the 'norm-L4' decimation of us.downsampling ----
+int sifsr_l4pool4(const float* x, float* out, int B, int H, int W, void* stream) {
+  if (!x || !out) return SIFSR_ERR_ARG;
+  return launch_l4pool4(x, out, B, H, W, S(stream));
+}

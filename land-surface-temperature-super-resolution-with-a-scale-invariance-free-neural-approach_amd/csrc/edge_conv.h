@@ -56,6 +56,7 @@ int launch_tiles_prepare(const float* lst, const float* ndvi, float* x, int T, i
                          float mean_lst, float std_lst, float mean_ndvi, float std_ndvi, int clip_ndvi, hipStream_t s);
 int launch_tiles_paste(const float* sr, float* out, int T, int tiles_x, int hr, long long out_row, float mean, float std,
                        hipStream_t s);
+int launch_l4pool4(const float* x, float* out, int B, int H, int W, hipStream_t s);
 size_t psnr_ssim_scratch_bytes(int B, int H, int W);
 int launch_psnr_ssim(const float* pred, const float* targ, int B, int H, int W, void* scratch, float* out2, hipStream_t s);
 

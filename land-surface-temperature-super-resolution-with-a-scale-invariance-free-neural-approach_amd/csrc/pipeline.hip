@@ -100,6 +100,25 @@ __global__ __launch_bounds__(256) void tiles_paste_kernel(const float* __restric
   }
 }
 
+// us.downsampling (utils.py:183-213), the 'norm-L4' decimation: (mean of x^4 over each 4x4 block)^(1/4)
+__global__ __launch_bounds__(256) void l4pool4_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W) {
+  const int Ho = H / 4, Wo = W / 4;
+  const size_t n = (size_t)B * Ho * Wo;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int ox = (int)(e % Wo);
+    const size_t r = e / Wo;
+    const int oy = (int)(r % Ho), b = (int)(r / Ho);
+    const float* src = x + ((size_t)b * H + 4 * oy) * W + 4 * ox;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = ld4(src + (size_t)i * W);
+      s += v.x * v.x * v.x * v.x; s += v.y * v.y * v.y * v.y; s += v.z * v.z * v.z * v.z; s += v.w * v.w * v.w * v.w;
+    }
+    out[e] = powf(s / 16.f, 0.25f);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // PSNR / SSIM
 // ---------------------------------------------------------------------------------------------
@@ -267,6 +286,16 @@ int launch_psnr_ssim(const float* pred, const float* targ, int B, int H, int W, 
   hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, s, mm, mmb);
   hipLaunchKernelGGL(psnr_ssim_tile_kernel, grid, dim3(256), 0, s, pred, targ, mm, H, W, part);
   hipLaunchKernelGGL(psnr_ssim_final_kernel, dim3(1), dim3(256), 0, s, part, (int)(grid.x * grid.y), B, H, W, mm, out2);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_l4pool4(const float* x, float* out, int B, int H, int W, hipStream_t s) {
+  if (B < 1 || H < 4 || W < 4 || H % 4 || W % 4) return SIFSR_ERR_SHAPE;
+  const size_t n = (size_t)B * (H / 4) * (W / 4);
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(l4pool4_kernel, dim3((int)blocks), dim3(256), 0, s, x, out, B, H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

@@ -42,6 +42,23 @@ class ModisDatasetB(Dataset):
         return np.expand_dims(lst, 0), np.expand_dims(lst_up, 0), np.expand_dims(ndvi, 0)
 
 
+class ModisDatasetB_scale_invariance(ModisDatasetB):
+    """Synthetic drop-in for ``dataset.ModisDatasetB_scale_invariance`` (dataset.py:145-263): same constructor
+    and ``.stats``; ``__getitem__`` returns (lst_4km_up (1,64,64), ndvi_1km (1,64,64), lst (1,64,64)) computed from
+    the synthetic (lst, ndvi) pair exactly as dataset.py:256-263 does (bicubic /4 of NDVI without blur, norm-L4
+    decimation of the de-normalised LST, bicubic x4 back, re-normalisation), with torch CPU ops."""
+
+    def __getitem__(self, idx):
+        lst, _, ndvi = super().__getitem__(idx)
+        lst_t, ndvi_t = torch.from_numpy(lst)[None], torch.from_numpy(ndvi)[None]
+        nd = F.interpolate(F.pad(ndvi_t, (4, 4, 4, 4), mode="reflect"), scale_factor=0.25, mode="bicubic")[:, :, 1:-1, 1:-1]
+        k = lst_t * self.stats["std_lst"] + self.stats["mean_lst"]
+        k = k.unfold(3, 4, 4).unfold(2, 4, 4).pow(4).sum((-1, -2)).div(16).pow(0.25)
+        up = F.interpolate(k, scale_factor=4, mode="bicubic", align_corners=False)
+        up = (up - self.stats["mean_lst"]) / self.stats["std_lst"]
+        return up[0].numpy(), nd[0].numpy(), lst
+
+
 def synthetic_device_batch(batch, device, seed=1234, hr=256):
     """BASELINE.md §3 bench inputs, generated once on the device: (lst, lst_up, ndvi)."""
     g = torch.Generator(device="cpu").manual_seed(seed)

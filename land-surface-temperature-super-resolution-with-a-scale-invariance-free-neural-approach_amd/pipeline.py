@@ -55,3 +55,45 @@ def tiles_to_granule(sr, out, tiles, window, stats):
     _lib.call("sifsr_tiles_paste", sr, out, ty, tx, window, out.shape[1] // 4, float(stats["mean_lst"]), float(stats["std_lst"]),
               _lib.stream_ptr(sr.device))
     return out
+
+
+def l4pool4(x):
+    """us.downsampling (utils.py:183-213): (mean of x**4 over 4x4 blocks)**0.25 of a (B,1,H,W) batch."""
+    _lib.require_gpu(x, "x")
+    B, c, H, W = x.shape
+    if c != 1:
+        raise _lib.SifsrError("l4pool4 expects (B,1,H,W)")
+    out = torch.empty((B, 1, H // 4, W // 4), dtype=torch.float32, device=x.device)
+    _lib.call("sifsr_l4pool4", x, out, B, H, W, _lib.stream_ptr(x.device))
+    return out
+
+
+_DELTA9 = None
+
+
+def decimate4_bic(x):
+    """us.downscale_LST_SR_to_LR_test(..., deci_type='bic') (utils.py:1716-1748): reflect-pad 4, bicubic /4, crop --
+    the consistency operator of the SIF loss WITHOUT the Gaussian blur (that function pads but never convolves).
+    Runs the fused blur+decimate kernel with an identity PSF.  (B,1,H,W), H and W multiples of 32, >= 64."""
+    import ctypes
+    global _DELTA9
+    if _DELTA9 is None:
+        _DELTA9 = (ctypes.c_float * 9)(0, 0, 0, 0, 1, 0, 0, 0, 0)
+    _lib.require_gpu(x, "x")
+    B, c, H, W = x.shape
+    out = torch.empty((B, c, H // 4, W // 4), dtype=torch.float32, device=x.device)
+    _lib.call("sifsr_gauss9_decimate4_fwd", x, _DELTA9, out, B * c, H, W, _lib.stream_ptr(x.device))
+    return out
+
+
+def scale_invariance_inputs(lst, ndvi, stats):
+    """ModisDatasetB_scale_invariance.__getitem__ (dataset.py:240-263) for a batch, on the device:
+    normalised lst (B,1,64,64) and ndvi (B,1,256,256) -> (lst_4km_up (B,1,64,64), ndvi_1km (B,1,64,64), lst).
+      ndvi_1km   = decimate4_bic(ndvi)
+      lst_4km    = l4pool4(lst*std + mean)                              [K, 16x16]
+      lst_4km_up = (bicubic x4 of lst_4km - mean) / std"""
+    ndvi_1km = decimate4_bic(ndvi)
+    lst_4km = l4pool4(lst * stats["std_lst"] + stats["mean_lst"])
+    x = prepare_tiles(lst_4km, ndvi_1km, {"mean_lst": stats["mean_lst"], "std_lst": stats["std_lst"], "mean_ndvi": 0.0,
+                                          "std_ndvi": 1.0})
+    return x[:, 0:1], x[:, 1:2], lst

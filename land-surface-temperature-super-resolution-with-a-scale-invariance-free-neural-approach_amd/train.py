@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 
 from . import distributed as dp
-from .sif_ops import sif_loss
+from .sif_ops import huber_loss, sif_loss
 
 
 def train_step(model, optimizer, lst, lst_up, ndvi, stats, alpha, gamma, kind="sr2", sync_grads=True):
@@ -36,3 +36,17 @@ def eval_step(model, lst, lst_up, ndvi, stats, alpha, gamma, kind="sr2"):
     model.eval()
     sr = model(torch.cat((lst_up, ndvi), dim=1))
     return sif_loss(kind, sr, lst, ndvi, stats["mean_lst"], stats["std_lst"], alpha, gamma)
+
+
+def si_train_step(model, optimizer, lst_4km_up, ndvi_1km, lst_1km, sync_grads=True):
+    """The scale-invariance baseline's step (train_model_B_scale_invariance.py:86-103): the model is trained one scale
+    down (4 km -> 1 km, 64x64 patches) with a plain ``nn.HuberLoss`` against the 1 km LST.  Returns the device loss."""
+    model.train()
+    optimizer.zero_grad(set_to_none=True)
+    sr = model(torch.cat((lst_4km_up, ndvi_1km), dim=1))
+    loss = huber_loss(sr, lst_1km)
+    loss.backward()
+    if sync_grads:
+        dp.allreduce_gradients(model, optimizer)
+    optimizer.step()
+    return loss

@@ -458,3 +458,30 @@ def frr_fro_fru(pb, rb, xb):
     fro = (rb - np.maximum(pb, rb)).sum() / rb.sum()
     fru = (xb - np.minimum(pb, xb)).sum() / xb.sum()
     return afr / pfr, fro, fru
+
+
+# ----------------------------------------------------------------------------------------------
+# Scale-invariance baseline (train_model_B_scale_invariance.py:86-103, dataset.py:240-263, utils.py:183-213,1716-1756)
+# ----------------------------------------------------------------------------------------------
+def downsampling_l4(img, scale=(4, 4)):
+    """utils.py:183-213: norm-L4 pooling, (mean of x^4 over each scale block)^(1/4)."""
+    img = img.unfold(dimension=3, size=scale[0], step=scale[0]).unfold(dimension=2, size=scale[1], step=scale[1])
+    return torch.pow(torch.sum(torch.pow(img, 4), dim=(-1, -2)) / (scale[0] * scale[1]), 0.25)
+
+
+def downscale_test(data, deci_type="bic"):
+    """utils.py:1716-1756 on a (B,1,H,W) tensor: reflect-pad 4 (the PSF is generated but never applied),
+    'bic': bicubic /4 + crop 1; 'norm-L4': crop the pad again + downsampling_l4."""
+    d = F.pad(data, (4, 4, 4, 4), mode="reflect")
+    if deci_type == "bic":
+        return F.interpolate(d, scale_factor=0.25, mode="bicubic")[:, :, 1:-1, 1:-1]
+    return downsampling_l4(d[:, :, 4:-4, 4:-4])
+
+
+def scale_invariance_inputs(lst, ndvi, stats):
+    """dataset.py:256-263 for a batch: normalised lst (B,1,64,64), ndvi (B,1,256,256) ->
+    (lst_4km_up, ndvi_1km, lst)."""
+    ndvi_1km = downscale_test(ndvi, "bic")
+    lst_4km = downscale_test(lst * stats["std_lst"] + stats["mean_lst"], "norm-L4")
+    up = F.interpolate(lst_4km, scale_factor=4, mode="bicubic", align_corners=False)     # us.upsampling (cv2 INTER_CUBIC)
+    return (up - stats["mean_lst"]) / stats["std_lst"], ndvi_1km, lst
