@@ -83,8 +83,8 @@ def cpu_baseline(kind, alpha, gamma, lr, mean, std, target_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="patches per GPU per step")
     ap.add_argument("--kind", default="sr2", choices=["sr2", "sr1"])
     ap.add_argument("--roofline-kernel", default="fwd_16x16_256", choices=sorted(ROOFLINE_KERNELS))

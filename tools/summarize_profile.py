@@ -71,6 +71,20 @@ for name, pattern, nth, per_step in [
     fr, wr = per_launch("fetch", pattern, nth, per_step), per_launch("write", pattern, nth, per_step)
     if fr is not None and wr is not None:
         traffic[name] = {"read_bytes": 2 * fr * 1024, "write_bytes": wr * 1024, "bytes": 2 * fr * 1024 + wr * 1024}
+# per-launch durations of the same launches from the kernel trace (what bench.py's HIP-event timing must agree with)
+trace = glob.glob(f"{src}/stats/*/*kernel_trace.csv")
+if trace:
+    trows = sorted(csv.DictReader(open(trace[0])), key=lambda r: int(r["Start_Timestamp"]))
+    for name, pattern, nth, per_step in [("fwd_16x16_256", "conv3x3_mfma_kernel<1, false>", 0, 6), ("fwd_32x16_256", "conv3x3_mfma_kernel<1, false>", 4, 6),
+                                         ("dgrad_16x16_256", "conv3x3_mfma_kernel<1, true>", 0, 5), ("wgrad_16x16_256", "conv3x3_wgrad_kernel<1, 1>", 0, 5)]:
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trows if pattern in r["Kernel_Name"]]
+        if len(d) >= per_step * steps and name in traffic:
+            pick = d[nth::per_step][:steps]
+            traffic[name]["avg_us_rocprofv3"] = sum(pick) / len(pick)
+    with open(f"profiles/{tag}_summary.md", "a") as fh:
+        fh.write("\n| roofline kernel (one launch) | avg µs (kernel trace) | HBM read MB | HBM write MB |\n|---|---|---|---|\n")
+        for name, t in traffic.items():
+            fh.write("| `%s` | %.1f | %.1f | %.1f |\n" % (name, t.get("avg_us_rocprofv3", float("nan")), t["read_bytes"] / 1e6, t["write_bytes"] / 1e6))
 json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tag {tag}; FETCH_SIZE doubled (gfx950)",
            "per_launch": traffic}, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
