@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--kind", default="sr2", choices=["sr2", "sr1"])
     ap.add_argument("--roofline-kernel", default="fwd_16x16_256", choices=sorted(ROOFLINE_KERNELS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = the headline fp32 path; bf16 = BASELINE.json config 5 (bf16 MFMA operands in the 3x3 conv "
+                         "forward / input-gradient, fp32 accumulation, storage and weight gradients) -- never the default")
     args = ap.parse_args()
 
     import sifsr
@@ -108,6 +111,7 @@ def main():
     stats = dict(sifsr.dataset.DEFAULT_STATS)
     torch.manual_seed(0)
     model = sifsr.ModelB_2(2, [16, 32, 64, 128], "replicate", "ReLU", 1, 1).to(dev)
+    model.compute_dtype = "bf16" if args.dtype == "bf16" else "fp32"
     opt = sifsr.FlatAdam(model.parameters(), lr=lr)
     lst, lst_up, ndvi = sifsr.dataset.synthetic_device_batch(args.batch, dev, seed=1234 + rank)
 
@@ -149,7 +153,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000 * dt / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.dtype == "f32" else "bf16 conv operands (fwd, dgrad), f32 accumulate/storage/wgrad", "data": "synthetic",
         "config": {"workload": f"ModelB SIF-NN-{kind.upper()} ({'gradFTM' if kind == 'sr2' else 'predef_filters'} loss) "
                                f"batch {args.batch}/GPU, synthetic 256x256, {world}x MI355X, fwd+loss+bwd+Adam",
                    "batch_per_gpu": args.batch, "patch": "256x256 (LST 64x64 + NDVI 256x256)",
@@ -159,15 +163,29 @@ def main():
         kavg_ms = kms.value / max(1, kcount.value)
         kt = kflops * args.batch / (kavg_ms * 1e-3) / 1e12 if kavg_ms > 0 else 0.0
         step_tf = TRAIN_FLOPS_PER_PATCH * per_gpu / 1e12
-        traffic, traffic_src = measured_traffic(args.roofline_kernel)
-        out["roofline"] = {
-            "bound": "mfma", "kernel": args.roofline_kernel, "achieved": round(kt, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(kt / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "HBM bytes/launch (PMC)", "traffic_source": traffic_src,
-            "kernel_avg_ms": round(kavg_ms, 4), "kernel_launches_timed": kcount.value,
-            "step": {"achieved": round(step_tf, 2), "frac": round(step_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                     "hbm_GBs_algorithmic": round(TRAIN_BYTES_PER_PATCH * per_gpu / 1e9, 1)},
-        }
+        traffic, traffic_src = measured_traffic(args.roofline_kernel) if args.dtype == "f32" else (None, None)
+        if args.dtype == "f32":
+            out["roofline"] = {
+                "bound": "mfma", "kernel": args.roofline_kernel, "achieved": round(kt, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(kt / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes/launch (PMC)", "traffic_source": traffic_src,
+                "kernel_avg_ms": round(kavg_ms, 4), "kernel_launches_timed": kcount.value,
+                "step": {"achieved": round(step_tf, 2), "frac": round(step_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "hbm_GBs_algorithmic": round(TRAIN_BYTES_PER_PATCH * per_gpu / 1e9, 1)},
+            }
+        else:
+            # bf16 operands: the matrix-core peak rises 16x, the bytes do not change (fp32 storage) -> HBM-bound
+            # (SURVEY.md §8 d).  Algorithmic bytes of the selected conv launch = its input + output activations.
+            cin, cout = {"16x16": (16, 16), "32x16": (32, 16)}[args.roofline_kernel.split("_")[1]]
+            kbytes = (cin + cout) * 256 * 256 * 4 * args.batch
+            gbs = kbytes / (kavg_ms * 1e-3) / 1e9 if kavg_ms > 0 else 0.0
+            out["roofline"] = {
+                "bound": "hbm", "kernel": args.roofline_kernel, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "kernel_avg_ms": round(kavg_ms, 4),
+                "kernel_launches_timed": kcount.value,
+                "step": {"hbm_GBs_algorithmic": round(TRAIN_BYTES_PER_PATCH * per_gpu / 1e9, 1),
+                         "frac": round(TRAIN_BYTES_PER_PATCH * per_gpu / 1e9 / PEAK_HBM_GBS, 4)},
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, alpha, gamma, lr, stats["mean_lst"], stats["std_lst"])
         print(json.dumps(out), flush=True)

@@ -50,6 +50,16 @@ SIFSR_API int sifsr_model_forward(const float* x, float* sr, const float* params
  * writes ALL 282,705 gradients ("=" semantics) into grads (same layout as params). */
 SIFSR_API int sifsr_model_backward(const float* x, const float* dsr, const float* params, float* grads,
                                    void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
+/* The same two calls with a compute mode: 0 = fp32 (identical to the calls above), 1 = BASELINE.json config 5,
+ * "bf16 mixed precision, MFMA-bf16 conv tiles": the operands of the sixteen 3x3 MFMA convs (activations after
+ * BatchNorm+ReLU, weights, and dy in the input-gradient pass) are rounded to bf16 while staging and contracted with
+ * v_mfma_f32_16x16x16_bf16; accumulation, stored activations, BatchNorm, the two thin convs, the weight gradients
+ * and the parameters stay fp32.  Forward and backward of one step must use the same mode. */
+SIFSR_API int sifsr_model_forward_ex(const float* x, float* sr, const float* params, float* running, long long* nbt,
+                                     void* workspace, size_t workspace_bytes, int B, int H, int W, int training,
+                                     float momentum, float eps, int compute, void* stream);
+SIFSR_API int sifsr_model_backward_ex(const float* x, const float* dsr, const float* params, float* grads, void* workspace,
+                                      size_t workspace_bytes, int B, int H, int W, int compute, void* stream);
 
 /* ---- 3x3 convolution pieces (nn.Conv2d(k=3,padding=1,padding_mode='replicate'), model.py:135,138,507) */
 /* OIHW -> MFMA fragment order: wfwd 9*cin*cout floats (forward operand); wdgrad 2*9*cin*cout floats
@@ -67,6 +77,14 @@ SIFSR_API int sifsr_conv3x3_fwd(const float* src0, int C0, const float* scale0, 
 SIFSR_API int sifsr_conv3x3_dgrad(const float* dy, int cout, const float* wdgrad, const float* w_oihw, int cin,
                                   float* g0, int C0, float* g1, int C1, const float* addend, int B, int H, int W,
                                   void* stream);
+/* bf16-operand forms of the two calls above (BASELINE.json config 5): operands rounded to bf16 while staging,
+ * v_mfma_f32_16x16x16_bf16, fp32 accumulation and output.  Both take the `wdgrad` buffer of
+ * sifsr_pack_conv_weights, whose second half holds the bf16 fragment packs [forward | dgrad]. */
+SIFSR_API int sifsr_conv3x3_fwd_bf16(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1,
+                                     int C1, const float* scale1, const float* shift1, const float* wdgrad, float* y,
+                                     int cout, float* stat_partials, int B, int H, int W, void* stream);
+SIFSR_API int sifsr_conv3x3_dgrad_bf16(const float* dy, int cout, const float* wdgrad, int cin, float* g0, int C0, float* g1,
+                                       int C1, const float* addend, int B, int H, int W, void* stream);
 SIFSR_API size_t sifsr_conv3x3_wgrad_scratch_floats(int cin, int cout, int nblk);
 /* dw (OIHW) = sum_pixels dy (x) a_in; deterministic 2-stage reduction through `scratch`. */
 SIFSR_API int sifsr_conv3x3_wgrad(const float* src0, int C0, const float* scale0, const float* shift0,

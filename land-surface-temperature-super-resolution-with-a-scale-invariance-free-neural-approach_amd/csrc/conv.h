@@ -30,6 +30,7 @@ struct ConvArgs {
   int dst_split;        // in 16-channel blocks
   int B, H, W;
   int NQ;               // 16-channel blocks of the contraction (Cin / 16)
+  int bf16 = 0;         // 1: wpack is the bf16 fragment pack, operands are rounded to bf16 (fp32 accumulate/outputs)
 };
 
 // conv3x3, stride 1, NHWC fp32, MFMA implicit GEMM.  zero_pad = 0: replicate padding (forward,
@@ -58,6 +59,6 @@ int launch_wgrad_reduce_batched(const float* ws, const WgradReduceJob* jobs, int
 // dgrad: replicate-padding adjoint fold for the border pixels (adds to g_in).  wdg_layer = the layer's
 // dgrad weight pack [fragment order | tap-major] written by pack_weights.
 int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, int Cin, float* g0, int C0,
-                            int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s);
+                            int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s, int bf16 = 0);
 
 int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStream_t s);

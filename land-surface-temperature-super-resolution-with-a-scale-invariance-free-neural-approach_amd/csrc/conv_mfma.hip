@@ -46,13 +46,32 @@ static __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigne
 }
 constexpr unsigned OOB = 0xFFFFFF00u;   // per-lane offset beyond any tensor: buffer loads return 0
 
+// ---- bf16 operand mode (BASELINE.json config 5: "bf16 mixed precision, MFMA-bf16 conv tiles") ----
+// Activations and weights stay fp32 in HBM; the producers round them to bf16 (RNE, v_cvt_pk_bf16_f32) while
+// staging, and ONE v_mfma_f32_16x16x16_bf16 contracts the 16 channels that take four v_mfma_f32_16x16x4_f32 in
+// the fp32 mode -- same lane map (lane (i, kq) holds channels 4kq..4kq+3), fp32 accumulation, fp32 outputs.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+static __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  bf16x2 p; p[0] = (__bf16)a; p[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, p);
+}
+static __device__ __forceinline__ uint2 pack_bf16x4(float4 v) { return make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+static __device__ __forceinline__ float round_bf16(float a) { return (float)(__bf16)a; }
+static __device__ __forceinline__ float4 round_bf16x4(float4 v) { return make_float4(round_bf16(v.x), round_bf16(v.y), round_bf16(v.z), round_bf16(v.w)); }
+static __device__ __forceinline__ uint2 bload2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+  return make_uint2(v.x, v.y);
+}
+
 // 512 threads = 8 waves, specialised by role (one of each per SIMD):
 //   waves 0-3  CONSUMERS: ds_read_b128 + MFMA over the staged buffer, then the tile epilogue (stores, statistics);
 //   waves 4-7  PRODUCERS: global loads of the next (tile, channel block) halo, BatchNorm+ReLU transform, LDS writes.
 // One s_barrier per work item hands a filled buffer to the consumers and a drained one back to the producers
 // (double-buffered LDS), so the producers' VALU / VMEM / LDS-write instructions issue in the shadow of the
 // consumers' 32-cycle MFMAs on the same SIMD instead of in a separate phase of the same wave.
-template <int NB, bool ZERO_PAD>
+template <int NB, bool ZERO_PAD, bool BF16>
 __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(const ConvArgs a, const int ntiles, const int lgx,
                                                            const int lgy) {
   constexpr int CBW = NB >= 4 ? NB / 4 : 1;                 // cout blocks per consumer wave
@@ -92,8 +111,10 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
     // staging map: thread -> (channel quad cg, 6 halo pixels).  Interior tiles: the 6 pixel offsets relative to
     // the halo origin are tile-independent constants; the tile position is a SCALAR offset.
     const int ptid = tid - 256;
-    const int cg = ptid & 3;
-    const int pslot = ptid >> 2;
+    // fp32: (channel quad fastest) -- measured equal to the conflict-free order, kept.  bf16: ds_write_b64 is
+    // serviced in groups of 16 contiguous lanes on a 32-dword bank row -> 16 consecutive pixels of ONE quad.
+    const int cg = BF16 ? (ptid >> 4) & 3 : ptid & 3;
+    const int pslot = BF16 ? ((ptid & 15) | ((ptid >> 6) << 4)) : ptid >> 2;
     int spy[6], spx[6], prel[6];
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
@@ -158,7 +179,10 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
       for (int it = 0; it < 6; ++it) {
         float4 v = stg[it];
         if (!praw) v = bn_relu4(v, psc, psh);
-        if (it < 5 || pslot < PW * PW - 320) Lb[cg * PLANE + pslot + 64 * it] = v;
+        if (it < 5 || pslot < PW * PW - 320) {
+          if (BF16) reinterpret_cast<uint2*>(Lb)[cg * PLANE + pslot + 64 * it] = pack_bf16x4(v);
+          else Lb[cg * PLANE + pslot + 64 * it] = v;
+        }
       }
     };
 
@@ -181,16 +205,23 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
   const __amdgpu_buffer_rsrc_t rd0 = make_rsrc(a.dst[0].ptr, npix * a.dst[0].C * 4u);
   const __amdgpu_buffer_rsrc_t rd1 = make_rsrc(a.dst[1].ptr, npix * a.dst[1].C * 4u);
   const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.addend ? a.addend : a.dst[0].ptr, npix * (a.addend ? a.addC : a.dst[0].C) * 4u);
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpack, (unsigned)(NB * 16) * (unsigned)(NQ * 16) * 36u);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpack, (unsigned)(NB * 16) * (unsigned)(NQ * 16) * (BF16 ? 18u : 36u));
 
-  float4 wf[CBW][9];
+  float4 wf[BF16 ? 1 : CBW][BF16 ? 1 : 9];
+  uint2 wh[BF16 ? CBW : 1][BF16 ? 9 : 1];     // bf16 mode: 4 bf16 per lane per (cout block, tap)
   auto load_weights = [&](int q) {
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
       const int nb = nb0 + 4 * c;
-      const unsigned soff = (unsigned)((nb * NQ + q) * 9) * 1024u;
+      if (BF16) {
+        const unsigned soff = (unsigned)((nb * NQ + q) * 9) * 512u;
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp) wf[c][tp] = bload4(rw, (unsigned)lane * 16u, soff + tp * 1024u);
+        for (int tp = 0; tp < 9; ++tp) wh[c][tp] = bload2(rw, (unsigned)lane * 8u, soff + tp * 512u);
+      } else {
+        const unsigned soff = (unsigned)((nb * NQ + q) * 9) * 1024u;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) wf[c][tp] = bload4(rw, (unsigned)lane * 16u, soff + tp * 1024u);
+      }
     }
   };
 
@@ -219,6 +250,29 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
 
     const float4* L = lds[buf];
     __builtin_amdgcn_s_setprio(1);
+    if (BF16) {
+      const uint2* L16 = reinterpret_cast<const uint2*>(L);
+#pragma unroll
+      for (int gb = 0; gb < NG / 4; ++gb) {
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          const int ty = tp / 3, tx = tp - 3 * (tp / 3);
+          s16x4 bh[4];
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi) {
+            const int r = g0 + gb * 4 + gi;
+            bh[gi] = __builtin_bit_cast(s16x4, L16[kq * PLANE + (r + ty) * PW + tx + px]);
+          }
+#pragma unroll
+          for (int c = 0; c < CBW; ++c) {
+            const s16x4 w = __builtin_bit_cast(s16x4, wh[c][tp]);
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi)
+              acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w, bh[gi], acc[c][gb * 4 + gi], 0, 0, 0);
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int gb = 0; gb < NG / 4; ++gb) {
 #pragma unroll
@@ -247,6 +301,7 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
             acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, bf[gi].w, acc[c][gb * 4 + gi], 0, 0, 0);
         }
       }
+    }
     }
     __builtin_amdgcn_s_setprio(0);
     buf ^= 1;
@@ -323,8 +378,8 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
 //   fwd  : wf[nb][q][tap][lane][j] = W[co = 16nb + (lane&15)][ci = 16q + 4(lane>>4) + j][tap]
 //   dgrad: wd[nb][q][tap][lane][j] = W[co = 16q + 4(lane>>4) + j][ci = 16nb + (lane&15)][8 - tap]
 //          (transposed and spatially flipped: dx[p] = sum_t W_t^T dy[p - t])
-//   border: wb[tap][co][ci] = W[co][ci][tap]   (tap-major, ci contiguous; used by dgrad_border_kernel)
-// The dgrad buffer of a layer holds [wd | wb] = 2 * 9*cin*cout floats.
+//   bf16 : the same two packs rounded to bf16 (config 5), [fwd16 | dgrad16] = 2 * 9*cin*cout bf16
+// The dgrad buffer of a layer holds [wd | fwd16 dgrad16] = 2 * 9*cin*cout floats.
 // ---------------------------------------------------------------------------------------------
 struct PackTable { int w_off[16], cin[16], cout[16], p_off[16]; };
 
@@ -351,8 +406,11 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
       wdg[2 * tb.p_off[l] + e] = W[(co * cin + ci) * 9 + (8 - tap)];
     }
     {
-      const int ci = e % cin, co = (e / cin) % cout, t = e / (cin * cout);
-      wdg[2 * tb.p_off[l] + n + e] = W[(co * cin + ci) * 9 + t];
+      // bf16 fragment packs (same element order): [fwd | dgrad], 2 bytes each, in the second half of the layer's
+      // dgrad buffer (n floats = 2n + 2n bytes)
+      __bf16* h = reinterpret_cast<__bf16*>(wdg + 2 * tb.p_off[l] + n);
+      h[e] = (__bf16)wfwd[tb.p_off[l] + e];
+      h[n + e] = (__bf16)wdg[2 * tb.p_off[l] + e];
     }
   }
 }
@@ -378,7 +436,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
 //     bottom-left: ((0,-1),(H-1,0)), ((+1,-1),(H-2,0)+(H-1,0))   bottom-right: mirrored.
 __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restrict__ dy, int Cout,
                                                            const float* __restrict__ wd, int Cin, float* g0, int C0,
-                                                           int split_ch, float* g1, int C1, int B, int H, int W) {
+                                                           int split_ch, float* g1, int C1, int B, int H, int W,
+                                                           int bf16) {
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int NBI = Cin / 16, NQ = Cout / 16;
@@ -398,7 +457,8 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   auto mac = [&](int tp_fwd, int q, float4 bv) {           // forward tap index tp_fwd = (ty+1)*3 + (tx+1)
-    const float4 w = ld4(wbase + ((size_t)q * 9 + (8 - tp_fwd)) * 256);
+    float4 w = ld4(wbase + ((size_t)q * 9 + (8 - tp_fwd)) * 256);
+    if (bf16) { w = round_bf16x4(w); bv = round_bf16x4(bv); }   // same products as the bf16 MFMA of the main kernel
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, bv.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, bv.y, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, bv.z, acc, 0, 0, 0);
@@ -423,13 +483,15 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
         const bool c = qx == 0;
         const float4 e = row(qy, 0, q), n = row(yin, 0, q);
         mac(1 * 3 + 0, q, c ? e : z4);
-        mac((ty + 1) * 3 + 0, q, c ? make_float4(e.x + n.x, e.y + n.y, e.z + n.z, e.w + n.w) : z4);
+        mac((ty + 1) * 3 + 0, q, c ? e : z4);
+        mac((ty + 1) * 3 + 0, q, c ? n : z4);
       }
       if (seg == seg_tb - 1) {                              // right corner lane (qx == W-1): taps (0,+1) and (ty,+1)
         const bool c = qx == W - 1;
         const float4 e = row(qy, W - 1, q), n = row(yin, W - 1, q);
         mac(1 * 3 + 2, q, c ? e : z4);
-        mac((ty + 1) * 3 + 2, q, c ? make_float4(e.x + n.x, e.y + n.y, e.z + n.z, e.w + n.w) : z4);
+        mac((ty + 1) * 3 + 2, q, c ? e : z4);
+        mac((ty + 1) * 3 + 2, q, c ? n : z4);
       }
     }
   } else {
@@ -489,8 +551,13 @@ int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s
   const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
 #define SIFSR_CONV_CASE(NBV)                                                                              \
   case NBV:                                                                                               \
-    if (zero_pad) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, true>), grid, block, 0, s, a, ntiles, lgx, lgy);     \
-    else hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, false>), grid, block, 0, s, a, ntiles, lgx, lgy);             \
+    if (a.bf16) {                                                                                         \
+      if (zero_pad) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, true, true>), grid, block, 0, s, a, ntiles, lgx, lgy);   \
+      else hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, false, true>), grid, block, 0, s, a, ntiles, lgx, lgy);           \
+    } else {                                                                                              \
+      if (zero_pad) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, true, false>), grid, block, 0, s, a, ntiles, lgx, lgy);  \
+      else hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, false, false>), grid, block, 0, s, a, ntiles, lgx, lgy);          \
+    }                                                                                                     \
     break;
   switch (nb) {
     SIFSR_CONV_CASE(1)
@@ -533,11 +600,11 @@ int launch_pack_weights_one(const float* w, int cin, int cout, float* wfwd, floa
 }
 
 int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, int Cin, float* g0, int C0,
-                            int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s) {
+                            int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s, int bf16) {
   if (H < 3 || W < 2 || Cin % 16 || Cout % 16) return SIFSR_ERR_SHAPE;
   const int waves = B * (2 * ((W + 15) / 16) + 2 * ((H - 2 + 15) / 16)) * (Cin / 16);
   hipLaunchKernelGGL(dgrad_border_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, dy, Cout, wdg_layer, Cin, g0, C0,
-                     split_ch, g1, C1, B, H, W);
+                     split_ch, g1, C1, B, H, W, bf16);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

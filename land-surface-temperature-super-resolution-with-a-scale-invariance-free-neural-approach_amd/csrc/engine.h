@@ -26,8 +26,9 @@ struct WsLayout {
 int sifsr_layout(int B, int H, int W, int training, WsLayout* out);
 
 int sifsr_engine_forward(const float* x, float* sr, const float* params, float* running, long long* nbt, float* ws,
-                         size_t ws_floats, int B, int H, int W, int training, float momentum, float eps, hipStream_t s);
+                         size_t ws_floats, int B, int H, int W, int training, float momentum, float eps, hipStream_t s,
+                         int bf16 = 0);
 int sifsr_engine_backward(const float* x, const float* dsr, const float* params, float* grads, float* ws,
-                          size_t ws_floats, int B, int H, int W, hipStream_t s);
+                          size_t ws_floats, int B, int H, int W, hipStream_t s, int bf16 = 0);
 int sifsr_engine_profile_select(int layer, int phase);
 int sifsr_engine_profile_read(float* total_ms, int* count);

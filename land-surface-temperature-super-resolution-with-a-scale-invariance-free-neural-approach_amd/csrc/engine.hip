@@ -126,6 +126,7 @@ struct Ctx {
   hipStream_t s;
   WgradReduceJob* jobs = nullptr;   // backward: slab reductions deferred to one batched launch
   int* njobs = nullptr;
+  int bf16 = 0;                     // config 5: bf16 MFMA operands in the 3x3 conv forward / dgrad
   int lvH(int lv) const { return H >> lv; }
   int lvW(int lv) const { return W >> lv; }
   float* f(size_t off) const { return ws + off; }
@@ -169,7 +170,11 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
   a.src[0] = s0; a.src[1] = s1;
   a.dst[0].ptr = c.f(c.lay.y[l]); a.dst[0].C = L.cout; a.dst[0].coff = 0;
   a.dst[1] = a.dst[0];
-  a.wpack = c.f(c.lay.wfwd) + L.wpack_off;
+  a.bf16 = c.bf16;
+  {
+    const size_t n = (size_t)9 * L.cin * L.cout;   // bf16 packs live in the second half of the layer's dgrad buffer
+    a.wpack = c.bf16 ? c.f(c.lay.wdg) + 2 * (size_t)L.wpack_off + n : c.f(c.lay.wfwd) + L.wpack_off;
+  }
   a.addend = nullptr; a.addC = 0;
   a.stat_partials = training ? c.f(c.lay.partials) : nullptr;
   a.dst_split = L.cout / 16;
@@ -241,7 +246,12 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
   a.src[0] = src_raw(dy, L.cout); a.src[1] = src_none();
   a.dst[0].ptr = g0; a.dst[0].C = C0; a.dst[0].coff = 0;
   a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
-  a.wpack = c.f(c.lay.wdg) + 2 * (size_t)L.wpack_off;
+  a.bf16 = c.bf16;
+  const float* wdg_f32 = c.f(c.lay.wdg) + 2 * (size_t)L.wpack_off;
+  {
+    const size_t n = (size_t)9 * L.cin * L.cout;
+    a.wpack = c.bf16 ? wdg_f32 + n + n / 2 : wdg_f32;   // [fp32 dgrad | bf16 fwd (n/2 floats) | bf16 dgrad]
+  }
   a.addend = addend; a.addC = L.cin;
   a.stat_partials = nullptr;
   a.dst_split = split_ch / 16;
@@ -251,8 +261,8 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
     ProfScope ps(l, 2, c.s);
     SIFSR_TRY(launch_conv3x3_mfma(a, L.cin, 1, c.s));
   }
-  SIFSR_TRY(launch_dgrad_border_fix(dy, L.cout, a.wpack, L.cin, g0, C0, split_ch, g1 ? g1 : g0, g1 ? C1 : C0, c.B, a.H,
-                                    a.W, c.s));
+  SIFSR_TRY(launch_dgrad_border_fix(dy, L.cout, wdg_f32, L.cin, g0, C0, split_ch, g1 ? g1 : g0, g1 ? C1 : C0, c.B, a.H,
+                                    a.W, c.s, c.bf16));
   return SIFSR_OK;
 }
 
@@ -263,9 +273,10 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
 // ---------------------------------------------------------------------------------------------
 int sifsr_engine_forward(const float* x, float* sr, const float* params, float* running, long long* nbt, float* ws,
                          size_t ws_floats, int B, int H, int W, int training, float momentum, float eps,
-                         hipStream_t s) {
+                         hipStream_t s, int bf16) {
   if (!x || !sr || !params || !running || !ws) return SIFSR_ERR_ARG;
   Ctx c{sifsr_net(), WsLayout(), ws, params, B, H, W, s};
+  c.bf16 = bf16 ? 1 : 0;
   SIFSR_TRY(sifsr_layout(B, H, W, training, &c.lay));
   if (ws_floats < c.lay.total) return SIFSR_ERR_WORKSPACE;
   const NetTable& nt = c.nt;
@@ -326,9 +337,10 @@ int sifsr_engine_forward(const float* x, float* sr, const float* params, float* 
 // backward (requires the workspace of the matching training-mode forward)
 // ---------------------------------------------------------------------------------------------
 int sifsr_engine_backward(const float* x, const float* dsr, const float* params, float* grads, float* ws,
-                          size_t ws_floats, int B, int H, int W, hipStream_t s) {
+                          size_t ws_floats, int B, int H, int W, hipStream_t s, int bf16) {
   if (!x || !dsr || !params || !grads || !ws) return SIFSR_ERR_ARG;
   Ctx c{sifsr_net(), WsLayout(), ws, params, B, H, W, s};
+  c.bf16 = bf16 ? 1 : 0;
   SIFSR_TRY(sifsr_layout(B, H, W, 1, &c.lay));
   if (ws_floats < c.lay.total) return SIFSR_ERR_WORKSPACE;
   const NetTable& nt = c.nt;

@@ -78,8 +78,10 @@ class _ModelFn(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         sr = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
         bn = module._bn_hyper
-        _lib.call("sifsr_model_forward", x, sr, flat_p, flat_r, flat_n, ws, ws_bytes, B, H, W,
-                  1 if training else 0, bn[0], bn[1], _lib.stream_ptr(x.device))
+        compute = 1 if getattr(module, "compute_dtype", "fp32") == "bf16" else 0
+        _lib.call("sifsr_model_forward_ex", x, sr, flat_p, flat_r, flat_n, ws, ws_bytes, B, H, W,
+                  1 if training else 0, bn[0], bn[1], compute, _lib.stream_ptr(x.device))
+        ctx.compute = compute
         ctx.module = module
         ctx.can_bwd = need_bwd
         ctx.training = training
@@ -104,7 +106,7 @@ class _ModelFn(torch.autograd.Function):
         dsr = dsr.contiguous()
         flat_p, _, _ = module._flat_state(dsr.device)
         grads = torch.empty_like(flat_p)
-        _lib.call("sifsr_model_backward", ctx.x, dsr, flat_p, grads, ctx.ws, ctx.ws.numel(), B, H, W,
+        _lib.call("sifsr_model_backward_ex", ctx.x, dsr, flat_p, grads, ctx.ws, ctx.ws.numel(), B, H, W, ctx.compute,
                   _lib.stream_ptr(dsr.device))
         ctx.ws = None
         ctx.x = None
@@ -139,6 +141,9 @@ class ModelB_2(nn.Module):
         self.activation = activation
         self.upfactor = 2 if bilinear else 1
         self.bridge = n_bridge_blocks
+        # not in the reference: 'fp32' (default, the parity path) or 'bf16' = BASELINE.json config 5, bf16 MFMA operands in
+        # the 3x3 convs (fp32 accumulation / storage / parameters) -- set the attribute, nothing else changes
+        self.compute_dtype = "fp32"
         d, uf = downchannels, self.upfactor
         self.inbloc = _Bloc(in_channels, d[0], None, padding_mode)          # model.py:596
         self.db1 = _Down(d[0], d[1], padding_mode)                           # :597

@@ -144,8 +144,39 @@ def _bn_relu(x, sd, bn, training):
     return F.relu(y)
 
 
+# BASELINE.json config 5 ("bf16 mixed precision, MFMA-bf16 conv tiles") as the build implements it: the operands of
+# the sixteen 3x3 convs that run on the matrix cores (everything but inbloc.bloc.0 and outlay) are rounded to bf16
+# (round-to-nearest-even), products accumulate in fp32, every stored tensor stays fp32.  Backward: the input
+# gradient contracts bf16(dy) with bf16(W); the weight gradient uses the unrounded x and dy.  The reference has no
+# mixed-precision code at all; torch.autocast(bfloat16) is the looser yardstick the tests also report.
+BF16_CONVS = False
+
+
+def _rbf(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _ConvBf16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return _conv3x3_rep(_rbf(x), _rbf(w))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        with torch.enable_grad():
+            xa = x.detach().requires_grad_(True)
+            (dx,) = torch.autograd.grad(_conv3x3_rep(xa, _rbf(w).detach()), xa, _rbf(dy))
+            wa = w.detach().requires_grad_(True)
+            (dw,) = torch.autograd.grad(_conv3x3_rep(x.detach(), wa), wa, dy)
+        return dx, dw
+
+
 def _conv_bn_relu(x, sd, conv, bn, training):
-    return _bn_relu(_conv3x3_rep(x, sd[conv + ".weight"]), sd, bn, training)
+    w = sd[conv + ".weight"]
+    y = _ConvBf16.apply(x, w) if (BF16_CONVS and w.shape[1] >= 16) else _conv3x3_rep(x, w)
+    return _bn_relu(y, sd, bn, training)
 
 
 def _double_conv(x, sd, prefix, training):
