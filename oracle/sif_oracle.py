@@ -11,6 +11,15 @@ build container, checks every function below against it on seeded inputs, and co
 vectors under ``tests/golden/``; ``tests/test_oracle_golden.py`` re-checks this file against those
 vectors on any machine.
 
+Rows next to the hot path (SURVEY.md §8 f), same file, pin status per row:
+  * Fourier-domain evaluation and the scale-invariance baseline's data transforms: PINNED by import
+    (``tests/golden/make_golden_fourier.py`` / ``make_golden_si.py`` run the reference's own functions);
+  * tile pipeline: the bicubic x4 of ``cv2.resize(INTER_CUBIC)`` is restated with ``F.interpolate`` and a
+    written-out cubic convolution -- OpenCV is not installed, parity with cv2 itself is UNPINNED;
+  * PSNR / SSIM: numpy/scipy restatement of scikit-image 0.22 -- scikit-image is not installed, UNPINNED;
+  * ``BF16_CONVS``: emulation of the build's bf16-operand mode (BASELINE.json config 5); the reference has no
+    mixed-precision code, so there is nothing to pin against.
+
 Every function cites the reference file:line it restates (paths relative to /root/reference).
 The restatement is *functional*: parameters and buffers live in plain dicts keyed by the
 reference's ``state_dict`` names, so the 104-key layout (SURVEY.md §8 b) is the oracle's own
