@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = the headline fp32 path; bf16 = BASELINE.json config 5 (bf16 MFMA operands in the 3x3 conv "
-                         "forward / input-gradient, fp32 accumulation, storage and weight gradients) -- never the default")
+                         "forward / input-gradient / weight-gradient passes, fp32 accumulation and storage) -- never the default")
     args = ap.parse_args()
 
     import sifsr
@@ -153,7 +153,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000 * dt / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "f32" else "bf16 conv operands (fwd, dgrad), f32 accumulate/storage/wgrad", "data": "synthetic",
+        "dtype": "f32" if args.dtype == "f32" else "bf16 conv operands (fwd, dgrad, wgrad), f32 accumulate/storage", "data": "synthetic",
         "config": {"workload": f"ModelB SIF-NN-{kind.upper()} ({'gradFTM' if kind == 'sr2' else 'predef_filters'} loss) "
                                f"batch {args.batch}/GPU, synthetic 256x256, {world}x MI355X, fwd+loss+bwd+Adam",
                    "batch_per_gpu": args.batch, "patch": "256x256 (LST 64x64 + NDVI 256x256)",

@@ -53,8 +53,8 @@ SIFSR_API int sifsr_model_backward(const float* x, const float* dsr, const float
 /* The same two calls with a compute mode: 0 = fp32 (identical to the calls above), 1 = BASELINE.json config 5,
  * "bf16 mixed precision, MFMA-bf16 conv tiles": the operands of the sixteen 3x3 MFMA convs (activations after
  * BatchNorm+ReLU, weights, and dy in the input-gradient pass) are rounded to bf16 while staging and contracted with
- * v_mfma_f32_16x16x16_bf16; accumulation, stored activations, BatchNorm, the two thin convs, the weight gradients
- * and the parameters stay fp32.  Forward and backward of one step must use the same mode. */
+ * v_mfma_f32_16x16x16_bf16 (the weight-gradient pass rounds x and dy the same way); accumulation, stored
+ * activations, BatchNorm, the two thin convs and the parameters stay fp32.  Forward and backward of one step must use the same mode. */
 SIFSR_API int sifsr_model_forward_ex(const float* x, float* sr, const float* params, float* running, long long* nbt,
                                      void* workspace, size_t workspace_bytes, int B, int H, int W, int training,
                                      float momentum, float eps, int compute, void* stream);
@@ -88,6 +88,12 @@ SIFSR_API int sifsr_conv3x3_dgrad_bf16(const float* dy, int cout, const float* w
 SIFSR_API size_t sifsr_conv3x3_wgrad_scratch_floats(int cin, int cout, int nblk);
 /* dw (OIHW) = sum_pixels dy (x) a_in; deterministic 2-stage reduction through `scratch`. */
 SIFSR_API int sifsr_conv3x3_wgrad(const float* src0, int C0, const float* scale0, const float* shift0,
+                                  const float* src1, int C1, const float* scale1, const float* shift1,
+                                  const float* dy, int cout, float* scratch, int nblk, float* dw, int B, int H, int W,
+                                  void* stream);
+/* bf16-operand form of the weight gradient (BASELINE.json config 5): the staged x and dy are rounded to bf16 when
+ * read from LDS and contracted 16 pixels at a time with v_mfma_f32_16x16x16_bf16; fp32 accumulation and slabs. */
+SIFSR_API int sifsr_conv3x3_wgrad_bf16(const float* src0, int C0, const float* scale0, const float* shift0,
                                   const float* src1, int C1, const float* scale1, const float* shift1,
                                   const float* dy, int cout, float* scratch, int nblk, float* dw, int B, int H, int W,
                                   void* stream);

@@ -158,6 +158,25 @@ int sifsr_conv3x3_wgrad(const float* src0, int C0, const float* scale0, const fl
   return launch_wgrad_reduce(scratch, nblk, cin, cout, wgrad_nbi_chunk(a, cin), dw, S(stream));
 }
 
+// bf16-operand form (config 5): x and dy rounded to bf16 when read from LDS, fp32 accumulation
+int sifsr_conv3x3_wgrad_bf16(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
+                        const float* scale1, const float* shift1, const float* dy, int cout, float* scratch, int nblk,
+                        float* dw, int B, int H, int W, void* stream) {
+  if (!src0 || C0 % 16 || (src1 && C1 % 16)) return SIFSR_ERR_SHAPE;
+  WgradArgs a;
+  a.src[0] = mk_src(src0, C0, scale0, shift0);
+  a.src[1] = mk_src(src1, C1, scale1, shift1);
+  a.dy = dy; a.slabs = scratch; a.B = B; a.H = H; a.W = W;
+  a.NQ = a.src[0].nq + a.src[1].nq;
+  a.ntiles = B * ((H + 7) / 8) * ((W + 15) / 16);
+  const int cin = 16 * a.NQ;
+  a.bf16 = 1;
+  if (nblk > a.ntiles) nblk = a.ntiles;
+  int rc = launch_conv3x3_wgrad(a, cin, cout, nblk, S(stream));
+  if (rc) return rc;
+  return launch_wgrad_reduce(scratch, nblk, cin, cout, wgrad_nbi_chunk(a, cin), dw, S(stream));
+}
+
 int sifsr_conv_in_fwd(const float* x, const float* w, float* y, float* stat_partials, int B, int H, int W, void* stream) {
   return launch_conv_in_fwd(x, w, y, stat_partials, B, H, W, S(stream));
 }

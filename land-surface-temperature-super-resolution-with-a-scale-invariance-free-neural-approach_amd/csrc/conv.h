@@ -45,7 +45,8 @@ struct WgradArgs {
   float* slabs;        // [nblk][chunks][9*cin_chunk*Cout] per-block partial dW in fragment order
   int B, H, W;
   int NQ;              // Cin / 16 (total)
-  int ntiles;          // B * (H/8) * (W/16)
+  int ntiles;          // B * ceil(H/8) * ceil(W/16)
+  int bf16 = 0;        // 1: operands rounded to bf16 when read from LDS, v_mfma_f32_16x16x16_bf16 (config 5)
 };
 // returns the number of slab blocks used through *nblk_out
 int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s);

@@ -28,7 +28,20 @@ static __device__ __forceinline__ float4 wg_bload4(__amdgpu_buffer_rsrc_t r, uns
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int NBO, int NBI>   // cout blocks, cin blocks handled by one workgroup (cin chunk = blockIdx.y)
+// bf16 operand mode (BASELINE.json config 5): the LDS tiles stay fp32; a wave reads the four 4-pixel k-steps of a
+// tile row (the same conflict-free ds_read_b32 pattern as the fp32 loop), rounds them to bf16 (RNE) and issues ONE
+// v_mfma_f32_16x16x16_bf16 over the row's 16 pixels where the fp32 mode issues four v_mfma_f32_16x16x4_f32.
+// K index 4*kg + j of the bf16 MFMA <-> pixel kg + 4*j of the row (any bijection works as long as A and B agree).
+typedef __attribute__((ext_vector_type(4))) short wg_s16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 wg_bf16x2;
+static __device__ __forceinline__ wg_s16x4 wg_pack4(float a, float b, float c, float d) {
+  wg_bf16x2 lo, hi;
+  lo[0] = (__bf16)a; lo[1] = (__bf16)b; hi[0] = (__bf16)c; hi[1] = (__bf16)d;
+  const uint2 u = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+  return __builtin_bit_cast(wg_s16x4, u);
+}
+
+template <int NBO, int NBI, bool BF16>   // cout blocks, cin blocks handled by one workgroup (cin chunk = blockIdx.y)
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, const int lgx, const int lgy) {
   constexpr int WO = NBO >= 2 ? 2 : 1, WI = NBI >= 2 ? 2 : 1, WP = 4 / (WO * WI);
   constexpr int NBO_W = NBO / WO, NBI_W = NBI / WI;
@@ -130,6 +143,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
   const int i16 = lane & 15, k = lane >> 4;
   const float* const a_base = lds_dy + (4 * wp + k) * CSO + 16 * (wo * NBO_W) + i16;
   const float* const b_base = lds_in + (4 * wp + k) * CSI + 16 * (wi * NBI_W) + i16;
+  const float* const a16_base = lds_dy + (wp * 16 + k) * CSO + 16 * (wo * NBO_W) + i16;       // bf16 mode: row wp, pixel k
+  const float* const b16_base = lds_in + (wp * WPW + k) * CSI + 16 * (wi * NBI_W) + i16;
 
   while (tile < a.ntiles) {
     __syncthreads();          // previous tile's MFMA reads are done
@@ -147,27 +162,55 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
     const int next = tile + gridDim.x;
     if (next < a.ntiles) issue(next);     // in flight during the MFMA phase below
 
+    if (BF16) {
+      // whole rows per wave: rows wp, wp + WP, ...; per row 4 reads per operand -> one bf16 MFMA per (o, i, tap)
+#pragma unroll
+      for (int jj = 0; jj < WT_ROWS / WP; ++jj) {
+        wg_s16x4 ah[NBO_W];
+#pragma unroll
+        for (int o = 0; o < NBO_W; ++o) {
+          const float* pa = a16_base + (WP * jj * 16) * CSO + 16 * o;
+          ah[o] = wg_pack4(pa[0], pa[4 * CSO], pa[8 * CSO], pa[12 * CSO]);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int tyy = t / 3, txx = t - 3 * (t / 3);
+          wg_s16x4 bh[NBI_W];
+#pragma unroll
+          for (int i = 0; i < NBI_W; ++i) {
+            const float* pb = b16_base + ((WP * jj + tyy) * WPW + txx) * CSI + 16 * i;
+            bh[i] = wg_pack4(pb[0], pb[4 * CSI], pb[8 * CSI], pb[12 * CSI]);
+          }
+#pragma unroll
+          for (int o = 0; o < NBO_W; ++o)
+#pragma unroll
+            for (int i = 0; i < NBI_W; ++i)
+              acc[o][i][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[o], bh[i], acc[o][i][t], 0, 0, 0);
+        }
+      }
+    } else {
     // k-steps ks = (row r, pixel quad qd) = j * WP + wp, fully unrolled: the wave-dependent part (4 * wp pixels)
-    // sits in the two base pointers, everything else is an immediate ds_read offset (no address arithmetic
-    // between the MFMAs, and the reads can be hoisted across k-steps).
-#pragma unroll
-    for (int j = 0; j < WT_ROWS * 4 / WP; ++j) {
-      const int r = WP == 4 ? j : (WP == 2 ? (j >> 1) : (j >> 2));
-      const int qc = WP == 4 ? 0 : (WP == 2 ? 2 * (j & 1) : (j & 3));
-      float av[NBO_W];
-#pragma unroll
-      for (int o = 0; o < NBO_W; ++o) av[o] = a_base[(r * 16 + 4 * qc) * CSO + 16 * o];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int tyy = t / 3, txx = t - 3 * (t / 3);
-        float bv[NBI_W];
-#pragma unroll
-        for (int i = 0; i < NBI_W; ++i) bv[i] = b_base[((r + tyy) * WPW + 4 * qc + txx) * CSI + 16 * i];
-#pragma unroll
-        for (int o = 0; o < NBO_W; ++o)
-#pragma unroll
-          for (int i = 0; i < NBI_W; ++i)
-            acc[o][i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[o], bv[i], acc[o][i][t], 0, 0, 0);
+      // sits in the two base pointers, everything else is an immediate ds_read offset (no address arithmetic
+      // between the MFMAs, and the reads can be hoisted across k-steps).
+  #pragma unroll
+      for (int j = 0; j < WT_ROWS * 4 / WP; ++j) {
+        const int r = WP == 4 ? j : (WP == 2 ? (j >> 1) : (j >> 2));
+        const int qc = WP == 4 ? 0 : (WP == 2 ? 2 * (j & 1) : (j & 3));
+        float av[NBO_W];
+  #pragma unroll
+        for (int o = 0; o < NBO_W; ++o) av[o] = a_base[(r * 16 + 4 * qc) * CSO + 16 * o];
+  #pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int tyy = t / 3, txx = t - 3 * (t / 3);
+          float bv[NBI_W];
+  #pragma unroll
+          for (int i = 0; i < NBI_W; ++i) bv[i] = b_base[((r + tyy) * WPW + 4 * qc + txx) * CSI + 16 * i];
+  #pragma unroll
+          for (int o = 0; o < NBO_W; ++o)
+  #pragma unroll
+            for (int i = 0; i < NBI_W; ++i)
+              acc[o][i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[o], bv[i], acc[o][i][t], 0, 0, 0);
+        }
       }
     }
     tile = next;
@@ -303,13 +346,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const float* 
   }
 }
 
-template <int NBO, int NBI>
+template <int NBO, int NBI, bool BF16>
 int launch_wgrad_t(const WgradArgs& a, int chunks, int nblk, hipStream_t s) {
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
   auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
   const int tx_ = (a.W + 15) / 16, ty_ = (a.H + WT_ROWS - 1) / WT_ROWS;
   const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<NBO, NBI>), dim3(nblk, chunks), dim3(256), 0, s, a, lgx, lgy);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<NBO, NBI, BF16>), dim3(nblk, chunks), dim3(256), 0, s, a, lgx, lgy);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
@@ -339,7 +382,7 @@ int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStr
     if (!pow2(a.src[0].C) || (a.src[1].ptr && !pow2(a.src[1].C))) return SIFSR_ERR_SHAPE;
   }
   const int nbi = wgrad_nbi_chunk(a, cin), chunks = (cin / 16) / nbi, nbo = cout / 16;
-#define SIFSR_WG(NBOV, NBIV) if (nbo == NBOV && nbi == NBIV) return launch_wgrad_t<NBOV, NBIV>(a, chunks, nblk, s);
+#define SIFSR_WG(NBOV, NBIV) if (nbo == NBOV && nbi == NBIV) return a.bf16 ? launch_wgrad_t<NBOV, NBIV, true>(a, chunks, nblk, s) : launch_wgrad_t<NBOV, NBIV, false>(a, chunks, nblk, s);
   SIFSR_WG(1, 1) SIFSR_WG(1, 2) SIFSR_WG(2, 1) SIFSR_WG(2, 2) SIFSR_WG(4, 2)
 #undef SIFSR_WG
   return SIFSR_ERR_SHAPE;

@@ -222,6 +222,7 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
   a.B = c.B; a.H = c.lvH(L.level); a.W = c.lvW(L.level);
   a.NQ = L.cin / 16;
   a.ntiles = c.B * ((a.H + 7) / 8) * ((a.W + 15) / 16);
+  a.bf16 = c.bf16;
   const int nbi = wgrad_nbi_chunk(a, L.cin);
   const int nblk = wgrad_blocks(L.cin, L.cout, L.cin / (16 * nbi), a.ntiles);
   {

@@ -156,7 +156,7 @@ def _bn_relu(x, sd, bn, training):
 # BASELINE.json config 5 ("bf16 mixed precision, MFMA-bf16 conv tiles") as the build implements it: the operands of
 # the sixteen 3x3 convs that run on the matrix cores (everything but inbloc.bloc.0 and outlay) are rounded to bf16
 # (round-to-nearest-even), products accumulate in fp32, every stored tensor stays fp32.  Backward: the input
-# gradient contracts bf16(dy) with bf16(W); the weight gradient uses the unrounded x and dy.  The reference has no
+# gradient contracts bf16(dy) with bf16(W); the weight gradient contracts bf16(x) with bf16(dy).  The reference has no
 # mixed-precision code at all; torch.autocast(bfloat16) is the looser yardstick the tests also report.
 BF16_CONVS = False
 
@@ -178,7 +178,7 @@ class _ConvBf16(torch.autograd.Function):
             xa = x.detach().requires_grad_(True)
             (dx,) = torch.autograd.grad(_conv3x3_rep(xa, _rbf(w).detach()), xa, _rbf(dy))
             wa = w.detach().requires_grad_(True)
-            (dw,) = torch.autograd.grad(_conv3x3_rep(x.detach(), wa), wa, dy)
+            (dw,) = torch.autograd.grad(_conv3x3_rep(_rbf(x).detach(), wa), wa, _rbf(dy))
         return dx, dw
 
 

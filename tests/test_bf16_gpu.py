@@ -99,6 +99,8 @@ def test_bf16_conv_kernels_exact_arithmetic(sifsr, case):
     y_ref = conv(rb(x), rb(w))
     xa = x.clone().requires_grad_(True)
     (gx_ref,) = torch.autograd.grad(conv(xa, rb(w)), xa, rb(dy))
+    wa = w.clone().requires_grad_(True)
+    (gw_ref,) = torch.autograd.grad(conv(rb(x), wa), wa, rb(dy))
     S = torch.cuda.current_stream().cuda_stream
     wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(2 * 9 * cin * cout, device="cuda")
     L.call("sifsr_pack_conv_weights", w.cuda(), cin, cout, wf, wd, S)
@@ -106,9 +108,14 @@ def test_bf16_conv_kernels_exact_arithmetic(sifsr, case):
     y = torch.empty(B, H, W, cout, device="cuda"); gx = torch.empty(B, H, W, cin, device="cuda")
     L.call("sifsr_conv3x3_fwd_bf16", nhwc(x), cin, None, None, None, 0, None, None, wd, y, cout, None, B, H, W, S)
     L.call("sifsr_conv3x3_dgrad_bf16", nhwc(dy), cout, wd, cin, gx, cin, None, 0, None, B, H, W, S)
+    nblk = 4
+    scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_scratch_floats", cin, cout, nblk), device="cuda")
+    gw = torch.empty_like(w, device="cuda")
+    L.call("sifsr_conv3x3_wgrad_bf16", nhwc(x), cin, None, None, None, 0, None, None, nhwc(dy), cout, scratch, nblk, gw, B, H, W, S)
     torch.cuda.synchronize()
     assert rel_err(y.permute(0, 3, 1, 2).cpu(), y_ref) < 1e-5
     assert rel_err(gx.permute(0, 3, 1, 2).cpu(), gx_ref) < 1e-5
+    assert rel_err(gw.cpu(), gw_ref) < 1e-5
 
 
 def test_bf16_train_steps_run_and_decrease_loss(sifsr):
