@@ -28,13 +28,17 @@ static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_ca
 
 // relu(fma(v, scale, shift)) on 4 channels: BatchNorm (folded to scale/shift) + ReLU applied when a
 // consumer loads a raw conv output (model.py:136-137 / :139-140).
+// Written on 2-vectors so that hipcc emits v_pk_fma_f32 / v_pk_max_f32 (two lanes of fp32 per instruction): on gfx950
+// every VALU instruction of ANY wave on a SIMD stalls that SIMD's matrix pipe for its duration
+// (tools/mfma_valu_coexec.hip: MFMA + VALU time = the sum, not the max), so the staging transform's instruction count
+// is paid in full inside the MFMA kernels.  Same fp32 results as the scalar form (fma then max, per element).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 static __device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh) {
-  float4 r;
-  r.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
-  r.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-  r.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
-  r.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-  return r;
+  const f32x2 z = {0.f, 0.f};
+  f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+  lo = __builtin_elementwise_max(__builtin_elementwise_fma(lo, (f32x2){sc.x, sc.y}, (f32x2){sh.x, sh.y}), z);
+  hi = __builtin_elementwise_max(__builtin_elementwise_fma(hi, (f32x2){sc.z, sc.w}, (f32x2){sh.z, sh.w}), z);
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 
 // ---------------------------------------------------------------------------------------------
