@@ -152,6 +152,37 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
+// Same, for sums produced by the dgrad epilogue + border kernel of the layer above (conv_mfma.hip): two partial arrays,
+// and the second sum is sum dz*y (not dz*xhat): sum dz*xhat = invstd * (sum dz*y - mean * sum dz), in float64.
+__global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __restrict__ pa, int na,
+                                                               const float* __restrict__ pb, int nb, int C, double count,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, float* dgamma,
+                                                               float* dbeta, double* coef) {
+  __shared__ double r1[256], r2[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = tid; k < na; k += 256) { s1 += (double)pa[((size_t)k * C + c) * 2]; s2 += (double)pa[((size_t)k * C + c) * 2 + 1]; }
+  for (int k = tid; k < nb; k += 256) { s1 += (double)pb[((size_t)k * C + c) * 2]; s2 += (double)pb[((size_t)k * C + c) * 2 + 1]; }
+  r1[tid] = s1; r2[tid] = s2;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) { r1[tid] += r1[tid + st]; r2[tid] += r2[tid + st]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double db = r1[0];
+    const double dg = (double)invstd[c] * (r2[0] - (double)mean[c] * db);
+    dbeta[c] = (float)db;
+    dgamma[c] = (float)dg;
+    const double k1 = -(double)scale[c] * (double)invstd[c] * dg / count;
+    coef[c] = (double)scale[c];
+    coef[C + c] = k1;
+    coef[2 * C + c] = -(double)scale[c] * db / count - k1 * (double)mean[c];
+  }
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                            const float* __restrict__ scale,
@@ -224,6 +255,14 @@ int launch_bn_bwd_finalize(const float* partials, int nblk, int C, double count,
                            const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, partials, nblk, C, count, scale, mean, invstd,
                      dgamma, dbeta, coef);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+int launch_bn_bwd_finalize2(const float* pa, int na, const float* pb, int nb, int C, double count, const float* scale,
+                            const float* mean, const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3(C), dim3(256), 0, s, pa, na, pb, nb, C, count, scale, mean, invstd, dgamma,
+                     dbeta, coef);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

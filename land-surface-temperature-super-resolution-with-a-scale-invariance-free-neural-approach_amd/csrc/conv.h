@@ -31,6 +31,12 @@ struct ConvArgs {
   int B, H, W;
   int NQ;               // 16-channel blocks of the contraction (Cin / 16)
   int bf16 = 0;         // 1: wpack is the bf16 fragment pack, operands are rounded to bf16 (fp32 accumulate/outputs)
+  // dgrad of a 16-channel layer whose output IS the gradient w.r.t. relu(bn(y)) of the previous layer: the epilogue
+  // also produces that layer's BatchNorm-backward sums (dz = g*[y*scale+shift > 0]; sum dz, sum dz*y per channel) into
+  // stat_partials, saving the separate reduce pass over (g, y).  bn_y = that layer's raw conv output (C = 16).
+  const float* bn_y = nullptr;
+  const float* bn_scale = nullptr;
+  const float* bn_shift = nullptr;
 };
 
 // conv3x3, stride 1, NHWC fp32, MFMA implicit GEMM.  zero_pad = 0: replicate padding (forward,
@@ -60,6 +66,9 @@ int launch_wgrad_reduce_batched(const float* ws, const WgradReduceJob* jobs, int
 // dgrad: replicate-padding adjoint fold for the border pixels (adds to g_in).  wdg_layer = the layer's
 // dgrad weight pack [fragment order | tap-major] written by pack_weights.
 int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, int Cin, float* g0, int C0,
-                            int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s, int bf16 = 0);
+                            int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s, int bf16 = 0,
+                            const float* bn_y = nullptr, const float* bn_scale = nullptr, const float* bn_shift = nullptr,
+                            float* bn_partials = nullptr);
+int dgrad_border_waves(int B, int H, int W, int Cin);   // rows of bn_partials ([wave][16][2]) the border kernel writes
 
 int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStream_t s);

@@ -205,6 +205,8 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
   const __amdgpu_buffer_rsrc_t rd0 = make_rsrc(a.dst[0].ptr, npix * a.dst[0].C * 4u);
   const __amdgpu_buffer_rsrc_t rd1 = make_rsrc(a.dst[1].ptr, npix * a.dst[1].C * 4u);
   const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.addend ? a.addend : a.dst[0].ptr, npix * (a.addend ? a.addC : a.dst[0].C) * 4u);
+  const bool bn_stats = NB == 1 && ZERO_PAD && a.bn_y != nullptr;     // BatchNorm-backward sums of the previous layer
+  const __amdgpu_buffer_rsrc_t rby = make_rsrc(bn_stats ? a.bn_y : a.dst[0].ptr, npix * 64u);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpack, (unsigned)(NB * 16) * (unsigned)(NQ * 16) * (BF16 ? 18u : 36u));
 
   float4 wf[BF16 ? 1 : CBW][BF16 ? 1 : 9];
@@ -316,7 +318,17 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
     // store is dropped, the addend reads 0) and stay out of the statistics; rows past H are skipped.
     const bool colok = txi * 16 + px < W;
     const int rows_ok = H - (tyi * 16 + g0);
-    const bool do_stats = a.stat_partials != nullptr;
+    const bool do_stats = a.stat_partials != nullptr && !bn_stats;
+    // y of the previous layer for this tile's rows (NB == 1: 4 rows per wave): issued first, consumed after the stores
+    // (prefetching them across the MFMA loop costs 16 live registers: spills at the 128-VGPR budget)
+    float4 yq[NB == 1 ? 4 : 1];
+    float4 bsc = make_float4(0.f, 0.f, 0.f, 0.f), bsh = bsc;
+    if (NB == 1 && bn_stats) {
+      bsc = ld4(a.bn_scale + 4 * kq); bsh = ld4(a.bn_shift + 4 * kq);   // reloaded per tile (L2 hits): not worth 8 live VGPRs
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        yq[g] = bload4(rby, (colok && g < rows_ok) ? (unsigned)px * 64u + (unsigned)kq * 16u : OOB, (tile_pix + (unsigned)(g * W)) * 64u);
+    }
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
       const int nb = nb0 + 4 * c;
@@ -337,7 +349,15 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
           v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
         }
         bstore4(rd, vo, rowpix * (unsigned)dC * 4u, make_float4(v[0], v[1], v[2], v[3]));
-        if (do_stats) {               // uniform: forward in training mode only (VALU work stalls the matrix pipe)
+        if (NB == 1 && bn_stats) {    // dz = g * [y*scale + shift > 0]; sum dz, sum dz*y (masked lanes read y = 0, v ignored)
+          const float yy[4] = {yq[g].x, yq[g].y, yq[g].z, yq[g].w};
+          const float scv[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, shv[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dz = (colok && fmaf(yy[r], scv[r], shv[r]) > 0.f) ? v[r] : 0.f;
+            s1[c][r] += dz; s2[c][r] = fmaf(dz, yy[r], s2[c][r]);
+          }
+        } else if (do_stats) {        // uniform: forward in training mode only (VALU work stalls the matrix pipe)
           if (!colok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int r = 0; r < 4; ++r) { s1[c][r] += v[r]; s2[c][r] = fmaf(v[r], v[r], s2[c][r]); }
@@ -440,7 +460,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
 __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restrict__ dy, int Cout,
                                                            const float* __restrict__ wd, int Cin, float* g0, int C0,
                                                            int split_ch, float* g1, int C1, int B, int H, int W,
-                                                           int bf16) {
+                                                           int bf16, const float* __restrict__ bn_y,
+                                                           const float* __restrict__ bn_scale,
+                                                           const float* __restrict__ bn_shift,
+                                                           float* __restrict__ bn_partials) {
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int NBI = Cin / 16, NQ = Cout / 16;
@@ -516,6 +539,32 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
     float4 v = ld4(dst);
     v.x += acc[0]; v.y += acc[1]; v.z += acc[2]; v.w += acc[3];
     st4(dst, v);
+  }
+  if (bn_partials != nullptr) {
+    // the BatchNorm-backward sums are linear in g: this wave adds (delta*mask, delta*mask*y) of its 16 border pixels
+    // for its 16 channels (Cin == 16 here, nb == 0); rows of bn_partials = global wave index
+    float d1[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      const size_t pix = (size_t)(b * H + qy) * W + qx;
+      const float4 yv = ld4(bn_y + pix * 16 + 4 * kq), sc = ld4(bn_scale + 4 * kq), sh = ld4(bn_shift + 4 * kq);
+      const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dz = fmaf(yy[r], scv[r], shv[r]) > 0.f ? acc[r] : 0.f;
+        d1[r] = dz; d2[r] = dz * yy[r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) { d1[r] += __shfl_xor(d1[r], m); d2[r] += __shfl_xor(d2[r], m); }
+    if (px == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bn_partials[((size_t)wave_g * 16 + 4 * kq + r) * 2 + 0] = d1[r];
+        bn_partials[((size_t)wave_g * 16 + 4 * kq + r) * 2 + 1] = d2[r];
+      }
+    }
   }
 }
 
@@ -602,12 +651,18 @@ int launch_pack_weights_one(const float* w, int cin, int cout, float* wfwd, floa
   return SIFSR_OK;
 }
 
+int dgrad_border_waves(int B, int H, int W, int Cin) {
+  return B * (2 * ((W + 15) / 16) + 2 * ((H - 2 + 15) / 16)) * (Cin / 16);
+}
+
 int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, int Cin, float* g0, int C0,
-                            int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s, int bf16) {
+                            int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s, int bf16,
+                            const float* bn_y, const float* bn_scale, const float* bn_shift, float* bn_partials) {
+  if (bn_partials != nullptr && (Cin != 16 || !bn_y || !bn_scale || !bn_shift)) return SIFSR_ERR_ARG;
   if (H < 3 || W < 2 || Cin % 16 || Cout % 16) return SIFSR_ERR_SHAPE;
   const int waves = B * (2 * ((W + 15) / 16) + 2 * ((H - 2 + 15) / 16)) * (Cin / 16);
   hipLaunchKernelGGL(dgrad_border_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, dy, Cout, wdg_layer, Cin, g0, C0,
-                     split_ch, g1, C1, B, H, W, bf16);
+                     split_ch, g1, C1, B, H, W, bf16, bn_y, bn_scale, bn_shift, bn_partials);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

@@ -35,6 +35,8 @@ int launch_bn_bwd_reduce(const float* g, const float* y, const float* scale, con
                          const float* gp = nullptr, int H = 0, int W = 0);
 int launch_bn_bwd_finalize(const float* partials, int nblk, int C, double count, const float* scale, const float* mean,
                            const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s);
+int launch_bn_bwd_finalize2(const float* pa, int na, const float* pb, int nb, int C, double count, const float* scale,
+                            const float* mean, const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s);
 int launch_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, const double* coef,
                         int C, size_t npix, float* dy, hipStream_t s, const float* gp = nullptr, int H = 0, int W = 0);
 int launch_nbt_increment(long long* nbt, int n, hipStream_t s);

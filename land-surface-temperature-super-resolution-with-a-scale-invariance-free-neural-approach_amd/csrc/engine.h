@@ -15,6 +15,7 @@ struct WsLayout {
   size_t partials;                        // BN statistic partials (scratch)
   size_t fwd_end;
   size_t coef;                            // BN-backward affine coefficients (3 x C float64, current layer)
+  size_t bpart;                           // BN-backward sums from the dgrad border kernel ([wave][16][2])
   size_t g[SIFSR_NUM_BN_LAYERS];          // grad w.r.t. relu(bn(y_l)), overwritten in place by dy_l
   size_t dyB[3];                          // dy of the residual blocks' second conv
   size_t gP[3], gU[3];

@@ -95,6 +95,7 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
   w.fwd_end = off;
   if (training) {
     w.coef = take(6 * 64);   // 3 x C float64 BN-backward coefficients of the layer being processed
+    w.bpart = take((size_t)dgrad_border_waves(B, H, W, 16) * 32);   // level 0 is the largest user
     for (int l = 0; l < SIFSR_NUM_BN_LAYERS; ++l) w.g[l] = take(nt.L[l].cout * N[nt.L[l].level]);
     w.dyB[0] = take(16 * N[1]); w.dyB[1] = take(32 * N[2]); w.dyB[2] = take(64 * N[3]);
     for (int k = 0; k < 3; ++k) w.gP[k] = take(pc[k] * N[k + 1]);
@@ -196,9 +197,23 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
 
 // BatchNorm+ReLU backward of unit l: g (grad w.r.t. relu(bn(y_l))) -> dy (grad w.r.t. y_l); dgamma/dbeta -> grads
 // gp != nullptr: g is completed on the fly by the AvgPool adjoint of the half-resolution gradient gp (bn.hip PoolAdj)
-int bn_unit_bwd(const Ctx& c, int l, const float* g, float* dy, float* grads, const float* gp = nullptr) {
+// fused_stats > 0: the sums were already produced by the dgrad (fused_stats = its workgroup count) + border kernel of the
+// layer above (conv_unit_dgrad with bn_layer), so the reduce pass over (g, y) is skipped.
+int bn_unit_bwd(const Ctx& c, int l, const float* g, float* dy, float* grads, const float* gp = nullptr,
+                int fused_stats = 0) {
   const LayerInfo& L = c.nt.L[l];
   const int lh = c.lvH(L.level), lw = c.lvW(L.level);
+  if (fused_stats > 0) {
+    const size_t npix = c.lay.npix[L.level];
+    SIFSR_TRY(launch_bn_bwd_finalize2(c.f(c.lay.partials), fused_stats, c.f(c.lay.bpart), dgrad_border_waves(c.B, lh, lw, 16),
+                                      L.cout, (double)npix, c.scale(l), c.f(c.lay.mean) + L.ch_off,
+                                      c.f(c.lay.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
+                                      reinterpret_cast<double*>(c.f(c.lay.coef)), c.s));
+    if (dy != nullptr)
+      SIFSR_TRY(launch_bn_bwd_apply(g, c.f(c.lay.y[l]), c.scale(l), c.shift(l), reinterpret_cast<const double*>(c.f(c.lay.coef)),
+                                    L.cout, npix, dy, c.s, gp, lh, lw));
+    return SIFSR_OK;
+  }
   const size_t npix = c.lay.npix[L.level];
   size_t nb = npix / 256;
   const int nblk = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
@@ -240,9 +255,15 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
 
 // input gradient of MFMA unit l: g_in = conv^T(dy) with the replicate-border fold.
 // Output channels [0, split_ch) -> (g0, C0); the rest -> (g1, C1).  addend (C = cin) is added to g0.
+// bn_layer >= 0: g0 is the complete gradient w.r.t. relu(bn(y_bn_layer)) (16 channels, no split, no addend): the kernel
+// and the border kernel also emit that layer's BatchNorm-backward sums; returns the number of partial rows through
+// *stat_rows (0 when the fusion does not apply).
 int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int split_ch, float* g1, int C1,
-                    const float* addend) {
+                    const float* addend, int bn_layer = -1, int* stat_rows = nullptr) {
   const LayerInfo& L = c.nt.L[l];
+  const bool fuse = bn_layer >= 0 && L.cin == 16 && C0 == 16 && split_ch == 16 && g1 == nullptr && addend == nullptr &&
+                    c.nt.L[bn_layer].cout == 16 && c.nt.L[bn_layer].level == L.level;
+  if (stat_rows) *stat_rows = 0;
   ConvArgs a;
   a.src[0] = src_raw(dy, L.cout); a.src[1] = src_none();
   a.dst[0].ptr = g0; a.dst[0].C = C0; a.dst[0].coff = 0;
@@ -258,12 +279,18 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
   a.dst_split = split_ch / 16;
   a.B = c.B; a.H = c.lvH(L.level); a.W = c.lvW(L.level);
   a.NQ = L.cout / 16;
+  if (fuse) {
+    a.stat_partials = c.f(c.lay.partials);
+    a.bn_y = c.f(c.lay.y[bn_layer]); a.bn_scale = c.scale(bn_layer); a.bn_shift = c.shift(bn_layer);
+    if (stat_rows) *stat_rows = conv3x3_grid_blocks(c.B, a.H, a.W, L.cin);
+  }
   {
     ProfScope ps(l, 2, c.s);
     SIFSR_TRY(launch_conv3x3_mfma(a, L.cin, 1, c.s));
   }
   SIFSR_TRY(launch_dgrad_border_fix(dy, L.cout, wdg_f32, L.cin, g0, C0, split_ch, g1 ? g1 : g0, g1 ? C1 : C0, c.B, a.H,
-                                    a.W, c.s, c.bf16));
+                                    a.W, c.s, c.bf16, fuse ? a.bn_y : nullptr, fuse ? a.bn_scale : nullptr,
+                                    fuse ? a.bn_shift : nullptr, fuse ? c.f(c.lay.bpart) : nullptr));
   return SIFSR_OK;
 }
 
@@ -378,9 +405,10 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     // second conv of the DoubleConvolution (k == 2: dy already produced by the fused tail above)
     if (k != 2) SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), c.f(w.g[lb]), grads));
     SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads));
-    SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), nt.L[la].cout, nt.L[lb].cin, nullptr, 0, nullptr));
+    int rows_a = 0;
+    SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), nt.L[la].cout, nt.L[lb].cin, nullptr, 0, nullptr, la, &rows_a));
     // first conv: input = cat([U_k, relu(bn(y_skip))])
-    SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), c.f(w.g[la]), grads));
+    SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), c.f(w.g[la]), grads, nullptr, rows_a));
     SIFSR_TRY(conv_unit_wgrad(c, la, src_raw(c.f(w.U[k]), uc[k]), src_act(c, ls), c.f(w.g[la]), grads));
     SIFSR_TRY(conv_unit_dgrad(c, la, c.f(w.g[la]), c.f(w.gU[k]), uc[k], uc[k], c.f(w.g[ls]), nt.L[ls].cout, nullptr));
     SIFSR_TRY(launch_up2x_bwd(c.f(w.gU[k]), c.f(w.g[ll]), B, c.lvH(lv + 1), c.lvW(lv + 1), uc[k], s));
@@ -397,12 +425,13 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     // iteration) is folded into this BatchNorm backward instead of a separate accumulate pass over g[lc].
     SIFSR_TRY(bn_unit_bwd(c, lc, c.f(w.g[lc]), c.f(w.g[lc]), grads, k < 2 ? c.f(w.gP[k + 1]) : nullptr));
     SIFSR_TRY(conv_unit_wgrad(c, lc, src_raw(c.f(w.R[k]), pc[k]), src_none(), c.f(w.g[lc]), grads));
-    SIFSR_TRY(conv_unit_dgrad(c, lc, c.f(w.g[lc]), c.f(w.g[lb]), pc[k], pc[k], nullptr, 0, nullptr));
+    int rows_b = 0, rows_a = 0;
+    SIFSR_TRY(conv_unit_dgrad(c, lc, c.f(w.g[lc]), c.f(w.g[lb]), pc[k], pc[k], nullptr, 0, nullptr, lb, &rows_b));
     // residual DoubleConvolution (g[lb] must survive as the skip gradient -> dy goes to dyB)
-    SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), c.f(w.dyB[k]), grads));
+    SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), c.f(w.dyB[k]), grads, nullptr, rows_b));
     SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.dyB[k]), grads));
-    SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.dyB[k]), c.f(w.g[la]), pc[k], pc[k], nullptr, 0, nullptr));
-    SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), c.f(w.g[la]), grads));
+    SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.dyB[k]), c.f(w.g[la]), pc[k], pc[k], nullptr, 0, nullptr, la, &rows_a));
+    SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), c.f(w.g[la]), grads, nullptr, rows_a));
     SIFSR_TRY(conv_unit_wgrad(c, la, src_raw(c.f(w.P[k]), pc[k]), src_none(), c.f(w.g[la]), grads));
     SIFSR_TRY(conv_unit_dgrad(c, la, c.f(w.g[la]), c.f(w.gP[k]), pc[k], pc[k], nullptr, 0, c.f(w.g[lb])));
     // AvgPool adjoint of gP[k] onto the skip gradient g[lp]: folded into the BatchNorm backward of lp (above / below)
@@ -412,20 +441,25 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   // inbloc
   SIFSR_TRY(bn_unit_bwd(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN3]), grads, c.f(w.gP[0])));
   SIFSR_TRY(conv_unit_wgrad(c, L_IN3, src_act(c, L_IN0), src_none(), c.f(w.g[L_IN3]), grads));
-  SIFSR_TRY(conv_unit_dgrad(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), 16, 16, nullptr, 0, nullptr));
+  int rows_in0 = 0;
+  SIFSR_TRY(conv_unit_dgrad(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), 16, 16, nullptr, 0, nullptr, L_IN0, &rows_in0));
   // first layer: no input gradient, so dy(L_IN0) is consumed by the weight gradient alone and is formed on the
-  // fly from (g, y) in its staging loop -- BatchNorm backward is reduce + finalize only
+  // fly from (g, y) in its staging loop; its BatchNorm-backward sums came out of the dgrad above -> finalize only
   {
     const LayerInfo& L = nt.L[L_IN0];
     const size_t npix = w.npix[0];
-    const size_t nb = npix / 256;
-    const int nblk_r = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
     const float* y = c.f(w.y[L_IN0]);
-    SIFSR_TRY(launch_bn_bwd_reduce(c.f(w.g[L_IN0]), y, c.scale(L_IN0), c.shift(L_IN0), c.f(w.mean) + L.ch_off,
-                                   c.f(w.invstd) + L.ch_off, 16, npix, c.f(w.partials), nblk_r, s));
-    SIFSR_TRY(launch_bn_bwd_finalize(c.f(w.partials), nblk_r, 16, (double)npix, c.scale(L_IN0), c.f(w.mean) + L.ch_off,
-                                     c.f(w.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
-                                     reinterpret_cast<double*>(c.f(w.coef)), s));
+    if (rows_in0 > 0) {
+      SIFSR_TRY(bn_unit_bwd(c, L_IN0, c.f(w.g[L_IN0]), nullptr, grads, nullptr, rows_in0));
+    } else {
+      const size_t nb = npix / 256;
+      const int nblk_r = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+      SIFSR_TRY(launch_bn_bwd_reduce(c.f(w.g[L_IN0]), y, c.scale(L_IN0), c.shift(L_IN0), c.f(w.mean) + L.ch_off,
+                                     c.f(w.invstd) + L.ch_off, 16, npix, c.f(w.partials), nblk_r, s));
+      SIFSR_TRY(launch_bn_bwd_finalize(c.f(w.partials), nblk_r, 16, (double)npix, c.scale(L_IN0), c.f(w.mean) + L.ch_off,
+                                       c.f(w.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
+                                       reinterpret_cast<double*>(c.f(w.coef)), s));
+    }
     int nblk = B * (H / 16) * (W / 16);
     if (nblk > 1024) nblk = 1024;
     SIFSR_TRY(launch_conv_in_wgrad_fused(x, c.f(w.g[L_IN0]), y, c.scale(L_IN0), c.shift(L_IN0),
