@@ -31,7 +31,9 @@ __device__ __forceinline__ void load_tile_reflect(float* L, const float* __restr
                                                   int x0, float a, float b, int tid) {
   for (int e = tid; e < TP * TP; e += 256) {
     const int py = e / TP, px = e - py * TP;
-    const int gy = refl(y0 - R + py, H), gx = refl(x0 - R + px, W);
+    // partial tiles reach past the image: clamp to the last halo coordinate (n-1+R) before reflecting; the LDS entries
+    // beyond it only feed outputs that are never stored
+    const int gy = refl(min(y0 - R + py, H - 1 + R), H), gx = refl(min(x0 - R + px, W - 1 + R), W);
     L[py * LS + px] = fmaf(a, img[(size_t)gy * W + gx], b);
   }
 }
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void blur_fwd_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int y = ty + 8 * r;
-    out[img + (size_t)(y0 + y) * W + x0 + tx] = vpass_at(M, k, y, tx);
+    if (y0 + y < H && x0 + tx < W) out[img + (size_t)(y0 + y) * W + x0 + tx] = vpass_at(M, k, y, tx);
   }
 }
 
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void blur_bwd_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int y = ty + 8 * r;
-    out[img + (size_t)(y0 + y) * W + x0 + tx] = vpass_adj_at(M, k, y, tx, y0, H);
+    if (y0 + y < H && x0 + tx < W) out[img + (size_t)(y0 + y) * W + x0 + tx] = vpass_adj_at(M, k, y, tx, y0, H);
   }
 }
 
@@ -161,7 +163,8 @@ __global__ __launch_bounds__(256) void blurdec_fwd_kernel(const float* __restric
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) s = fmaf(k4(a) * k4(b), Bt[(4 * i + a) * LS + 4 * j + b], s);
-    out[(size_t)blockIdx.z * (H / 4) * (W / 4) + (size_t)(y0 / 4 + i) * (W / 4) + x0 / 4 + j] = s;
+    if (y0 / 4 + i < H / 4 && x0 / 4 + j < W / 4)
+      out[(size_t)blockIdx.z * (H / 4) * (W / 4) + (size_t)(y0 / 4 + i) * (W / 4) + x0 / 4 + j] = s;
   }
 }
 
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void blurdec_bwd_kernel(const float* __restric
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int y = ty + 8 * r;
-    out[img + (size_t)(y0 + y) * W + x0 + tx] = vpass_adj_at(M, k, y, tx, y0, H);
+    if (y0 + y < H && x0 + tx < W) out[img + (size_t)(y0 + y) * W + x0 + tx] = vpass_adj_at(M, k, y, tx, y0, H);
   }
 }
 
@@ -454,27 +457,32 @@ inline int ew_grid(size_t n) { size_t b = (n + 255) / 256; return (int)(b > 8192
 
 #define SIFSR_CHECK_IMG(H, W) if ((H) % T || (W) % T || (H) < 2 * T || (W) < 2 * T) return SIFSR_ERR_SHAPE
 
+// The four unfused operators take any image of at least 2R+2 = 10 pixels a side (the two reflect zones of the adjoint must not overlap; the
+// decimating pair needs multiples of 4): partial tiles are masked.  The fused training loss keeps whole 32x32 tiles.
+#define SIFSR_CHECK_ANY(H, W, M) if ((H) < 2 * R + 2 || (W) < 2 * R + 2 || (H) % (M) || (W) % (M) || B < 1 || B > 65535) return SIFSR_ERR_SHAPE
+#define SIFSR_TGRID(H, W, B) dim3(((W) + T - 1) / T, ((H) + T - 1) / T, B)
+
 int launch_blur_fwd(const float* x, const float* taps9, float* out, int B, int H, int W, hipStream_t s) {
-  SIFSR_CHECK_IMG(H, W);
-  hipLaunchKernelGGL(blur_fwd_kernel, dim3(W / T, H / T, B), dim3(256), 0, s, x, out, make_taps(taps9), H, W);
+  SIFSR_CHECK_ANY(H, W, 1);
+  hipLaunchKernelGGL(blur_fwd_kernel, SIFSR_TGRID(H, W, B), dim3(256), 0, s, x, out, make_taps(taps9), H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
 int launch_blur_bwd(const float* g, const float* taps9, float* out, int B, int H, int W, hipStream_t s) {
-  SIFSR_CHECK_IMG(H, W);
-  hipLaunchKernelGGL(blur_bwd_kernel, dim3(W / T, H / T, B), dim3(256), 0, s, g, out, make_taps(taps9), H, W);
+  SIFSR_CHECK_ANY(H, W, 1);
+  hipLaunchKernelGGL(blur_bwd_kernel, SIFSR_TGRID(H, W, B), dim3(256), 0, s, g, out, make_taps(taps9), H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
 int launch_blurdec_fwd(const float* x, const float* taps9, float* out, int B, int H, int W, hipStream_t s) {
-  SIFSR_CHECK_IMG(H, W);
-  hipLaunchKernelGGL(blurdec_fwd_kernel, dim3(W / T, H / T, B), dim3(256), 0, s, x, out, make_taps(taps9), H, W);
+  SIFSR_CHECK_ANY(H, W, 4);
+  hipLaunchKernelGGL(blurdec_fwd_kernel, SIFSR_TGRID(H, W, B), dim3(256), 0, s, x, out, make_taps(taps9), H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
 int launch_blurdec_bwd(const float* glr, const float* taps9, float* out, int B, int H, int W, hipStream_t s) {
-  SIFSR_CHECK_IMG(H, W);
-  hipLaunchKernelGGL(blurdec_bwd_kernel, dim3(W / T, H / T, B), dim3(256), 0, s, glr, out, make_taps(taps9), H, W);
+  SIFSR_CHECK_ANY(H, W, 4);
+  hipLaunchKernelGGL(blurdec_bwd_kernel, SIFSR_TGRID(H, W, B), dim3(256), 0, s, glr, out, make_taps(taps9), H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
