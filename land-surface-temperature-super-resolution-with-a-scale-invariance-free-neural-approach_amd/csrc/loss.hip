@@ -350,10 +350,12 @@ __global__ __launch_bounds__(256) void sif_loss_fwd_kernel(const float* __restri
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) s = fmaf(k4(a) * k4(b), N[(4 * i + a) * LS + 4 * j + b], s);
-    const size_t o = (size_t)blockIdx.z * (H / 4) * (W / 4) + (size_t)(y0 / 4 + i) * (W / 4) + x0 / 4 + j;
-    const float e = (s - mean) / std - lst[o];
-    h1 = huber_val(e);
-    r1[o] = w1 * clamp1(e);
+    if (y0 / 4 + i < H / 4 && x0 / 4 + j < W / 4) {          // partial tiles: only pixels of the image count
+      const size_t o = (size_t)blockIdx.z * (H / 4) * (W / 4) + (size_t)(y0 / 4 + i) * (W / 4) + x0 / 4 + j;
+      const float e = (s - mean) / std - lst[o];
+      h1 = huber_val(e);
+      r1[o] = w1 * clamp1(e);
+    }
   }
   __syncthreads();
 
@@ -376,13 +378,16 @@ __global__ __launch_bounds__(256) void sif_loss_fwd_kernel(const float* __restri
       const int y = ty + 8 * r;
       const float hn = L[(y + R) * LS + tx + R] - vpass_at(M, k2, y, tx);
       const float e = hs[r] - gamma * hn;
-      h2 += huber_val(e);
-      r2[img + (size_t)(y0 + y) * W + x0 + tx] = w2 * clamp1(e);
+      if (y0 + y < H && x0 + tx < W) {
+        h2 += huber_val(e);
+        r2[img + (size_t)(y0 + y) * W + x0 + tx] = w2 * clamp1(e);
+      }
     }
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int y = y0 + ty + 8 * r, x = x0 + tx;
+      if (y >= H || x >= W) continue;
       float nb[9], a[4], c[4];
       neigh9_zero(sr + img, H, W, y, x, nb);
       sobel4(nb, a);
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(256) void sif_loss_bwd_kernel(const float* __restri
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int yy = y - (t / 3 - 1), xx = x - (t % 3 - 1);
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        if (y < H && x < W && yy >= 0 && yy < H && xx >= 0 && xx < W) {
           const float4 g = ld4(r2 + (img + (size_t)yy * W + xx) * 4);
           s += F[0][t] * g.x + F[1][t] * g.y + F[2][t] * g.z + F[3][t] * g.w;
         }
@@ -447,7 +452,8 @@ __global__ __launch_bounds__(256) void sif_loss_bwd_kernel(const float* __restri
     }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) dsr[img + (size_t)(y0 + ty + 8 * r) * W + x0 + tx] = acc[r];
+  for (int r = 0; r < 4; ++r)
+    if (y0 + ty + 8 * r < H && x0 + tx < W) dsr[img + (size_t)(y0 + ty + 8 * r) * W + x0 + tx] = acc[r];
 }
 
 inline Taps make_taps(const float* t9) { Taps k; for (int i = 0; i < 9; ++i) k.w[i] = t9[i]; return k; }
@@ -455,10 +461,9 @@ inline int ew_grid(size_t n) { size_t b = (n + 255) / 256; return (int)(b > 8192
 
 }  // namespace
 
-#define SIFSR_CHECK_IMG(H, W) if ((H) % T || (W) % T || (H) < 2 * T || (W) < 2 * T) return SIFSR_ERR_SHAPE
 
 // The four unfused operators take any image of at least 2R+2 = 10 pixels a side (the two reflect zones of the adjoint must not overlap; the
-// decimating pair needs multiples of 4): partial tiles are masked.  The fused training loss keeps whole 32x32 tiles.
+// decimating pair and the fused training loss need multiples of 4): partial tiles are masked.
 #define SIFSR_CHECK_ANY(H, W, M) if ((H) < 2 * R + 2 || (W) < 2 * R + 2 || (H) % (M) || (W) % (M) || B < 1 || B > 65535) return SIFSR_ERR_SHAPE
 #define SIFSR_TGRID(H, W, B) dim3(((W) + T - 1) / T, ((H) + T - 1) / T, B)
 
@@ -511,24 +516,24 @@ int launch_huber_bwd(const float* a, const float* b, float bscale, const float* 
 }
 
 size_t sif_loss_workspace_floats(int kind, int B, int H, int W) {
-  const size_t hr = (size_t)B * H * W, lr = hr / 16, nblk = (size_t)B * (H / T) * (W / T);
+  const size_t hr = (size_t)B * H * W, lr = hr / 16, nblk = (size_t)B * ((H + T - 1) / T) * ((W + T - 1) / T);
   return lr + (kind == 1 ? 4 * hr : hr) + 2 * nblk;
 }
 
 int launch_sif_loss(int kind, const float* sr, const float* lst, const float* ndvi, int B, int H, int W, float mean,
                     float std, float alpha, float gamma, const float* taps_ds, const float* taps_ftm, float* ws,
                     float* losses3, float* dsr, hipStream_t s) {
-  SIFSR_CHECK_IMG(H, W);
+  SIFSR_CHECK_ANY(H, W, 4);
   if (kind != 1 && kind != 2) return SIFSR_ERR_ARG;
   const size_t hr = (size_t)B * H * W, lr = hr / 16;
-  const int nblk = B * (H / T) * (W / T);
+  const int nblk = B * ((H + T - 1) / T) * ((W + T - 1) / T);
   float* r1 = ws;
   float* r2 = r1 + lr;
   float* partials = r2 + (kind == 1 ? 4 * hr : hr);
   const double n1 = (double)lr, n2 = kind == 1 ? 4.0 * (double)hr : (double)hr;
   const float w1 = (float)((double)alpha / n1), w2 = (float)((1.0 - (double)alpha) / n2);
   const Taps k1 = make_taps(taps_ds), k2 = make_taps(taps_ftm);
-  const dim3 grid(W / T, H / T, B);
+  const dim3 grid = SIFSR_TGRID(H, W, B);
   if (kind == 2) {
     hipLaunchKernelGGL((sif_loss_fwd_kernel<2>), grid, dim3(256), 0, s, sr, lst, ndvi, k1, k2, mean, std, gamma, w1, w2, r1, r2, partials, H, W);
   } else {

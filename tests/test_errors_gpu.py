@@ -63,8 +63,9 @@ def test_python_layer_errors():
     with pytest.raises(NotImplementedError):
         sifsr.downscale_LST_SR_to_LR(torch.zeros(1, 1, 64, 64, device="cuda"), deci_type="norm-L4")
     with pytest.raises(sifsr.SifsrError):
-        sifsr.sif_loss("sr2", torch.zeros(1, 1, 48, 48, device="cuda"),   # the FUSED loss needs whole 32x32 tiles (>= 64) torch.zeros(1, 1, 12, 12, device="cuda"),
-                       torch.zeros(1, 1, 48, 48, device="cuda"), 300.0, 5.0, 0.5, -0.25)
+        # the /4 decimation needs multiples of 4
+        sifsr.sif_loss("sr2", torch.zeros(1, 1, 50, 48, device="cuda"), torch.zeros(1, 1, 12, 12, device="cuda"),
+                       torch.zeros(1, 1, 50, 48, device="cuda"), 300.0, 5.0, 0.5, -0.25)
     # eval-mode backward is refused loudly, not silently wrong
     m.eval()
     y = m(torch.zeros(1, 2, 64, 64, device="cuda", requires_grad=True))

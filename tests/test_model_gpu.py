@@ -315,9 +315,9 @@ def test_other_patch_sizes(sifsr, shape):
     lst = torch.from_numpy(rs.standard_normal((B, 1, H // 4, W // 4)).astype(np.float32))
     ndvi = torch.from_numpy(np.clip(rs.standard_normal((B, 1, H, W)), -3, 3).astype(np.float32))
     lst_up = torch.nn.functional.interpolate(lst, scale_factor=4, mode="bicubic", align_corners=False)
-    # the fused SIF loss kernels work on whole 32x32 tiles (>= 64): smaller / other sizes use the plain Huber of the
-    # scale-invariance baseline (train_model_B_scale_invariance.py:98), which is what trains on 64x64 patches
-    kind = "sr2" if (H % 32 == 0 and W % 32 == 0 and H >= 64 and W >= 64 and H != 64) else "si"
+    # 64x64 is the scale-invariance baseline's patch size: its plain Huber (train_model_B_scale_invariance.py:98);
+    # every other size runs the SR2 loss (its kernels mask partial 32x32 tiles)
+    kind = "si" if H == 64 else "sr2"
     sr_o, (ds_o, pl_o, loss_o), _ = O.forward_backward(copy.deepcopy(sd), lst, lst_up, ndvi, MEAN, STD, 0.5, -0.25, kind)
     sr, (ds, pl, loss), g, masks, m = _hip_forward_backward(sifsr, sd, lst, lst_up, ndvi, 0.5, -0.25, kind)
     assert rel_err(sr, sr_o) < TOL

@@ -314,12 +314,13 @@ def test_loss_operators(L, hw):
     assert rel_err(gh, go) < TOL
 
 
+@pytest.mark.parametrize("hw", [(256, 256), (48, 80), (32, 32), (100, 36)])
 @pytest.mark.parametrize("kind,alpha,gamma", [("sr2", 0.5, -0.25), ("sr1", 0.99, -0.5), ("sr2", 0.1, -0.4)])
-def test_fused_sif_loss(L, kind, alpha, gamma):
+def test_fused_sif_loss(L, kind, alpha, gamma, hw):
     import sifsr
     from oracle import sif_oracle as O
     rs = np.random.RandomState(6)
-    B, H, W = 2, 256, 256
+    B, (H, W) = 2, hw
     sr = (rnd(rs, B, 1, H, W) * 1.3).requires_grad_(True)     # |e| > 1 on a fraction: both Huber branches
     lst = rnd(rs, B, 1, H // 4, W // 4)
     ndvi = rnd(rs, B, 1, H, W).clamp(-3, 3)
@@ -330,7 +331,7 @@ def test_fused_sif_loss(L, kind, alpha, gamma):
     ds, pl, loss = sifsr.sif_loss(kind, srd, lst.cuda(), ndvi.cuda(), mean, std, alpha, gamma)
     (g,) = torch.autograd.grad(loss, srd)
     for got, ref in ((ds, ds_o), (pl, pl_o), (loss, loss_o)):
-        assert abs(float(got) - float(ref)) < TOL * abs(float(ref)), (kind, float(got), float(ref))
+        assert abs(float(got.detach()) - float(ref.detach())) < TOL * abs(float(ref.detach())), (kind, float(got.detach()), float(ref.detach()))
     assert rel_err(g, g_o) < TOL
 
 
