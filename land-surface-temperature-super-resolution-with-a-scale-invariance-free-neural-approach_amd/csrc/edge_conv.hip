@@ -38,9 +38,15 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
     for (int k = 0; k < 18; ++k) s = fmaf(w[co * 18 + k], in[k], s);   // w is OIHW: [co][ci][t]
     o[co] = s;
   }
-  float* yp = y + ((size_t)(b * H + y0 + ty) * W + x0 + tx) * 16;
+  const bool inside = y0 + ty < H && x0 + tx < W;       // partial tiles when H or W is not a multiple of 16
+  if (inside) {
+    float* yp = y + ((size_t)(b * H + y0 + ty) * W + x0 + tx) * 16;
 #pragma unroll
-  for (int c4 = 0; c4 < 4; ++c4) st4(yp + 4 * c4, make_float4(o[4 * c4], o[4 * c4 + 1], o[4 * c4 + 2], o[4 * c4 + 3]));
+    for (int c4 = 0; c4 < 4; ++c4) st4(yp + 4 * c4, make_float4(o[4 * c4], o[4 * c4 + 1], o[4 * c4 + 2], o[4 * c4 + 3]));
+  } else {
+#pragma unroll
+    for (int co = 0; co < 16; ++co) o[co] = 0.f;          // stays out of the BatchNorm statistics
+  }
 
   if (partials != nullptr) {
     // transpose through LDS: thread (co = tid & 15, seg = tid >> 4) sums 16 pixels of one channel, then a
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restr
   __shared__ float dyt[256 * 16];
   __shared__ float red[4][2][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_x = W / 16, tiles_y = H / 16, ntiles = B * tiles_x * tiles_y;
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16, ntiles = B * tiles_x * tiles_y;
   const int i16 = lane & 15, k = lane >> 4;
   int offn[2];
 #pragma unroll
@@ -116,6 +122,10 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restr
     }
     for (int e = tid; e < 256 * 4; e += 256) {
       const int p = e >> 2, c4 = e & 3;
+      if (y0 + (p >> 4) >= H || x0 + (p & 15) >= W) {     // outside the image: contributes nothing
+        *reinterpret_cast<float4*>(&dyt[p * 16 + 4 * c4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+        continue;
+      }
       const size_t off = ((size_t)(b * H + y0 + (p >> 4)) * W + x0 + (p & 15)) * 16 + 4 * c4;
       float4 v = ld4(dy + off);
       if (FUSED) {
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_out_fwd_kernel(const float* __restri
       s = fmaf(w[(4 * c4 + 3) * 9 + t], v.w, s);
     }
   }
-  out[(size_t)(b * H + y0 + ty) * W + x0 + tx] = s;
+  if (y0 + ty < H && x0 + tx < W) out[(size_t)(b * H + y0 + ty) * W + x0 + tx] = s;
 }
 
 // output conv input-gradient: g[q][ci] = sum_t w[ci][t] * sum_{p: clamp(p+t)=q} dsr[p]  (replicate adjoint)
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(256) void conv_out_wgrad_kernel(const float* __rest
   __shared__ float red[4][256];
   __shared__ float bsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_x = W / 16, tiles_y = H / 16, ntiles = B * tiles_x * tiles_y;
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16, ntiles = B * tiles_x * tiles_y;
   const int i16 = lane & 15, k = lane >> 4;
   const int tty = i16 < 9 ? i16 / 3 : 100, ttx = i16 < 9 ? i16 % 3 : 100;   // lanes j >= 9: always out of range -> 0
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(256) void conv_out_wgrad_kernel(const float* __rest
       if (scale != nullptr) v = bn_relu4(v, ld4(scale + 4 * c4), ld4(shift + 4 * c4));
       *reinterpret_cast<float4*>(&tile[(py * 20 + px) * OCS + 4 * c4]) = v;
     }
-    const float dv = dsr[(size_t)(b * H + y0 + (tid >> 4)) * W + x0 + (tid & 15)];
+    const float dv = (y0 + (tid >> 4) < H && x0 + (tid & 15) < W) ? dsr[(size_t)(b * H + y0 + (tid >> 4)) * W + x0 + (tid & 15)] : 0.f;
     dt[tid] = dv;
     bacc += dv;
     __syncthreads();
@@ -309,15 +319,15 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 }  // namespace
 
 int launch_conv_in_fwd(const float* x, const float* w, float* y, float* partials, int B, int H, int W, hipStream_t s) {
-  if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
-  hipLaunchKernelGGL(conv_in_fwd_kernel, dim3(W / 16, H / 16, B), dim3(256), 0, s, x, w, y, partials, H, W);
+  if (H < 1 || W < 1) return SIFSR_ERR_SHAPE;
+  hipLaunchKernelGGL(conv_in_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16, B), dim3(256), 0, s, x, w, y, partials, H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
 
 int launch_conv_in_wgrad(const float* x, const float* dy, float* partials, int nblk, float* dw, int B, int H, int W,
                          hipStream_t s) {
-  if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
+  if (H < 1 || W < 1) return SIFSR_ERR_SHAPE;
   hipLaunchKernelGGL((conv_in_wgrad_kernel<false>), dim3(nblk), dim3(256), 0, s, x, dy, nullptr, nullptr, nullptr, nullptr,
                      partials, B, H, W);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(72), dim3(256), 0, s, partials, nblk, 288, dw);
@@ -328,7 +338,7 @@ int launch_conv_in_wgrad(const float* x, const float* dy, float* partials, int n
 int launch_conv_in_wgrad_fused(const float* x, const float* g, const float* y, const float* scale, const float* shift,
                                const double* coef, float* partials, int nblk, float* dw, int B, int H, int W,
                                hipStream_t s) {
-  if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
+  if (H < 1 || W < 1) return SIFSR_ERR_SHAPE;
   hipLaunchKernelGGL((conv_in_wgrad_kernel<true>), dim3(nblk), dim3(256), 0, s, x, g, y, scale, shift, coef, partials, B, H, W);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(72), dim3(256), 0, s, partials, nblk, 288, dw);
   SIFSR_LAUNCH_CHECK();
@@ -337,8 +347,8 @@ int launch_conv_in_wgrad_fused(const float* x, const float* g, const float* y, c
 
 int launch_conv_out_fwd(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
                         float* out, int B, int H, int W, hipStream_t s) {
-  if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
-  hipLaunchKernelGGL(conv_out_fwd_kernel, dim3(W / 16, H / 16, B), dim3(256), 0, s, y, scale, shift, w, bias, out, H, W);
+  if (H < 1 || W < 1) return SIFSR_ERR_SHAPE;
+  hipLaunchKernelGGL(conv_out_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16, B), dim3(256), 0, s, y, scale, shift, w, bias, out, H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
@@ -354,7 +364,7 @@ int launch_conv_out_dgrad(const float* dsr, const float* w, float* g, int B, int
 
 int launch_conv_out_wgrad(const float* y, const float* scale, const float* shift, const float* dsr, float* partials,
                           int nblk, float* dw, float* db, int B, int H, int W, hipStream_t s) {
-  if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
+  if (H < 1 || W < 1) return SIFSR_ERR_SHAPE;
   hipLaunchKernelGGL(conv_out_wgrad_kernel, dim3(nblk), dim3(256), 0, s, y, scale, shift, dsr, partials, B, H, W);
   // dw (144 floats) and db (1 float) are adjacent in the flat gradient buffer (outlay.weight, outlay.bias)
   if (db != dw + 144) return SIFSR_ERR_ARG;

@@ -62,9 +62,9 @@ static int wgrad_blocks(int cin, int cout, int chunks, int ntiles) {
 }
 
 int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
-  // three 2x poolings + exact x2 upsamplings back: H, W multiples of 8 (model.py:597-603); the thin first / last
-  // convs work on whole 16x16 tiles, and the deepest level must still have a 3x3 neighbourhood and >= 2 rows
-  if (B < 1 || H < 32 || W < 32 || H % 16 || W % 16) return SIFSR_ERR_SHAPE;
+  // three 2x poolings + exact x2 upsamplings back: H, W multiples of 8 (model.py:597-603), as in the reference; the
+  // deepest level (H/8 x W/8) must still have a 3x3 neighbourhood
+  if (B < 1 || H < 24 || W < 24 || H % 8 || W % 8) return SIFSR_ERR_SHAPE;
   const NetTable& nt = sifsr_net();
   WsLayout& w = *o;
   size_t off = 0;
@@ -87,7 +87,8 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
   // scratch: BN statistic partials (forward: one entry per conv workgroup; backward: <= 1024 blocks)
   size_t maxpart = 0;
   for (int l = 0; l < SIFSR_NUM_BN_LAYERS; ++l) {
-    const size_t nblk = N[nt.L[l].level] / 256;
+    const int lh = H >> nt.L[l].level, lw = W >> nt.L[l].level;
+    const size_t nblk = (size_t)B * ((lh + 15) / 16) * ((lw + 15) / 16);   // 16x16 tiles, the last row / column partial
     const size_t n = (nblk > 1024 ? nblk : 1024) * nt.L[l].cout * 2;
     maxpart = n > maxpart ? n : maxpart;
   }
@@ -322,7 +323,7 @@ int sifsr_engine_forward(const float* x, float* sr, const float* params, float* 
     const LayerInfo& L = nt.L[L_IN0];
     SIFSR_TRY(launch_conv_in_fwd(x, params + L.w_off, c.f(w.y[L_IN0]), training ? c.f(w.partials) : nullptr, B, H, W, s));
     if (training)
-      SIFSR_TRY(launch_bn_finalize(c.f(w.partials), B * (H / 16) * (W / 16), 16, (double)B * H * W, params + L.gamma_off,
+      SIFSR_TRY(launch_bn_finalize(c.f(w.partials), B * ((H + 15) / 16) * ((W + 15) / 16), 16, (double)B * H * W, params + L.gamma_off,
                                    params + L.beta_off, running + L.run_off, running + L.run_off + 16, momentum, eps,
                                    c.f(w.mean) + L.ch_off, c.f(w.invstd) + L.ch_off, c.f(w.scale) + L.ch_off,
                                    c.f(w.shift) + L.ch_off, s));
@@ -381,7 +382,7 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   // input gradient is recomputed from dsr in both passes instead of being stored; dy(L_U3B) -> g[L_U3B]
   {
     const LayerInfo& L = nt.L[L_U3B];
-    int nblk = B * (H / 16) * (W / 16);
+    int nblk = B * ((H + 15) / 16) * ((W + 15) / 16);
     if (nblk > 1024) nblk = 1024;
     const float* y = c.f(w.y[L_U3B]);
     SIFSR_TRY(launch_tail_bwd_reduce(y, c.scale(L_U3B), c.shift(L_U3B), c.f(w.mean) + L.ch_off, c.f(w.invstd) + L.ch_off, dsr,
@@ -460,7 +461,7 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
                                        c.f(w.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
                                        reinterpret_cast<double*>(c.f(w.coef)), s));
     }
-    int nblk = B * (H / 16) * (W / 16);
+    int nblk = B * ((H + 15) / 16) * ((W + 15) / 16);
     if (nblk > 1024) nblk = 1024;
     SIFSR_TRY(launch_conv_in_wgrad_fused(x, c.f(w.g[L_IN0]), y, c.scale(L_IN0), c.shift(L_IN0),
                                          reinterpret_cast<const double*>(c.f(w.coef)), c.f(w.slabs), nblk,

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_reduce_kernel(const float* __
   __shared__ float bsum[4];
   __shared__ double dred[4][4][8];        // [wave][channel quad][sum dz x4 | sum dz*y x4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_x = W / 16, tiles_y = H / 16, ntiles = B * tiles_x * tiles_y;
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16, ntiles = B * tiles_x * tiles_y;   // last ones may be partial
   const int i16 = lane & 15, k = lane >> 4;
 
   // ---- outlay dW operands
@@ -198,9 +198,10 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_reduce_kernel(const float* __
       }
       const float4 yv = *reinterpret_cast<const float4*>(&tile[((ly + 1) * 20 + lx + 1) * OCS + 4 * k]);
       const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+      const bool inside = y0 + ly < H && x0 + lx < W;      // partial tiles: pixels past the image stay out of the sums
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float dz = fmaf(yy[j], scv[j], shv[j]) > 0.f ? g[j] : 0.f;
+        const float dz = (inside && fmaf(yy[j], scv[j], shv[j]) > 0.f) ? g[j] : 0.f;
         t1[j] += dz;
         t2[j] = fmaf(dz, yy[j], t2[j]);
       }
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(256) void tail_bwd_apply_kernel(const float* __rest
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int p = pass * 64 + pl, ly = p >> 4, lx = p & 15;
+    if (y0 + ly >= H || x0 + lx >= W) continue;
     const size_t off = ((size_t)(b * H + y0 + ly) * W + x0 + lx) * 16 + 4 * c4;
     const float4 yv = ld4(y + off);
     float S[9];
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(256) void tail_bwd_apply_kernel(const float* __rest
 int launch_tail_bwd_reduce(const float* y, const float* scale, const float* shift, const float* mean, const float* invstd,
                            const float* dsr, const float* w, float* wpart, float* bnpart, int nblk, int B, int H, int W,
                            hipStream_t s) {
-  if (H % 16 || W % 16 || nblk < 1) return SIFSR_ERR_SHAPE;
+  if (H < 3 || W < 3 || nblk < 1) return SIFSR_ERR_SHAPE;
   hipLaunchKernelGGL(tail_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, s, y, scale, shift, mean, invstd, dsr, w, wpart,
                      bnpart, B, H, W);
   SIFSR_LAUNCH_CHECK();
@@ -293,8 +295,8 @@ int launch_tail_bwd_reduce(const float* y, const float* scale, const float* shif
 
 int launch_tail_bwd_apply(const float* y, const float* scale, const float* shift, const double* coef, const float* dsr,
                           const float* w, float* dy, int B, int H, int W, hipStream_t s) {
-  if (H % 16 || W % 16) return SIFSR_ERR_SHAPE;
-  hipLaunchKernelGGL(tail_bwd_apply_kernel, dim3(W / 16, H / 16, B), dim3(256), 0, s, y, scale, shift, coef, dsr, w, dy, H, W);
+  if (H < 3 || W < 3) return SIFSR_ERR_SHAPE;
+  hipLaunchKernelGGL(tail_bwd_apply_kernel, dim3((W + 15) / 16, (H + 15) / 16, B), dim3(256), 0, s, y, scale, shift, coef, dsr, w, dy, H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

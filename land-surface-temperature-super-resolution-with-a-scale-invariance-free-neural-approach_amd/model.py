@@ -66,9 +66,9 @@ class _ModelFn(torch.autograd.Function):
         B, C, H, W = x.shape
         if C != 2:
             raise _lib.SifsrError(f"ModelB_2 expects (B,2,H,W) = cat(lst_up, ndvi); got {tuple(x.shape)}")
-        if H % 16 or W % 16 or H < 32 or W < 32:
-            raise _lib.SifsrError("H and W must be multiples of 16 and >= 32 (the reference needs multiples of 8; its "
-                                  "patches are 256x256, 64x64 in the scale-invariance baseline)")
+        if H % 8 or W % 8 or H < 24 or W < 24:
+            raise _lib.SifsrError("H and W must be multiples of 8 (three 2x poolings, as in the reference) and >= 24; the "
+                                  "reference's patches are 256x256, 64x64 in the scale-invariance baseline")
         flat_p, flat_r, flat_n = module._flat_state(x.device)
         training = bool(module.training)
         need_bwd = training and any(ctx.needs_input_grad)   # grad mode is off inside forward(); this is the caller's

@@ -71,7 +71,9 @@ def test_workspace_sizes(L):
     # activations: conv outputs 27.5 MiB + pooled/residual/upsampled 10.5 MiB per patch (SURVEY.md §8 a)
     assert 38 * 2**20 < inf < 48 * 2**20
     assert L.call("sifsr_model_workspace_bytes", 64, 256, 256, 1) > 30 * trn   # fixed-size scratch (slabs) amortises
-    assert L.call("sifsr_model_workspace_bytes", 1, 200, 256, 1) == 0          # not a multiple of 128
+    assert L.call("sifsr_model_workspace_bytes", 1, 200, 256, 1) > 0           # any multiples of 8 (>= 24), as the reference
+    assert L.call("sifsr_model_workspace_bytes", 1, 204, 256, 1) == 0          # not a multiple of 8
+    assert L.call("sifsr_model_workspace_bytes", 1, 16, 256, 1) == 0           # too small for three poolings + a 3x3 window
     assert L.call("sifsr_model_workspace_bytes", 0, 256, 256, 1) == 0
     reg = (ctypes.c_size_t * 56)()
     assert L.call("sifsr_model_workspace_regions", 2, 256, 256, reg, 56) == 56

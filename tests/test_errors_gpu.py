@@ -32,9 +32,9 @@ def test_c_abi_status_codes(lib):
     assert ok == 0
     assert f(None, P(sr), P(p), P(r), P(n), P(ws), nbytes, 1, 64, 64, 0, 0.1, 1e-5, ctypes.c_void_p(S)) == ARG
     assert f(P(x), P(sr), P(p), P(r), P(n), P(ws), nbytes // 2, 1, 64, 64, 0, 0.1, 1e-5, ctypes.c_void_p(S)) == WORKSPACE
-    assert f(P(x), P(sr), P(p), P(r), P(n), P(ws), nbytes, 1, 60, 64, 0, 0.1, 1e-5, ctypes.c_void_p(S)) == SHAPE
+    assert f(P(x), P(sr), P(p), P(r), P(n), P(ws), nbytes, 1, 60, 64, 0, 0.1, 1e-5, ctypes.c_void_p(S)) == SHAPE   # not a multiple of 8
     assert f(P(x), P(sr), P(p), P(r), P(n), P(ws), nbytes, 0, 64, 64, 0, 0.1, 1e-5, ctypes.c_void_p(S)) == SHAPE
-    assert lib.sifsr_model_workspace_bytes(1, 24, 64, 1) == 0          # unsupported shape: no workspace size
+    assert lib.sifsr_model_workspace_bytes(1, 20, 64, 1) == 0          # unsupported shape: no workspace size
     # backward needs the training workspace of a training forward
     g = torch.zeros_like(p)
     assert lib.sifsr_model_backward(P(x), P(sr), P(p), P(g), P(ws), nbytes, 1, 64, 64, ctypes.c_void_p(S)) == WORKSPACE
@@ -58,7 +58,7 @@ def test_python_layer_errors():
     with pytest.raises(sifsr.SifsrError):
         m(torch.zeros(1, 3, 64, 64, device="cuda"))     # channels
     with pytest.raises(sifsr.SifsrError):
-        m(torch.zeros(1, 2, 40, 64, device="cuda"))     # not a multiple of 16
+        m(torch.zeros(1, 2, 44, 64, device="cuda"))     # not a multiple of 8
     assert m(torch.zeros(1, 2, 64, 64, device="cuda", dtype=torch.float64)).dtype == torch.float32   # converted, as .float()
     with pytest.raises(NotImplementedError):
         sifsr.downscale_LST_SR_to_LR(torch.zeros(1, 1, 64, 64, device="cuda"), deci_type="norm-L4")

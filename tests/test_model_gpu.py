@@ -303,11 +303,12 @@ def test_graph_captured_inference(sifsr, golden):
     assert rel_err(out2, ref2) < TOL
 
 
-@pytest.mark.parametrize("shape", [(2, 128, 384), (3, 64, 64), (2, 48, 80), (1, 32, 32)])
+@pytest.mark.parametrize("shape", [(2, 128, 384), (3, 64, 64), (2, 48, 80), (1, 32, 32), (2, 40, 72), (1, 24, 24)])
 def test_other_patch_sizes(sifsr, shape):
     """128 x 384: tile grids 8x24 / 4x12 / ... (not powers of two: generic tile-index paths, borders on all sides).
     64 x 64 (the scale-invariance baseline's patches), 48 x 80, 32 x 32: the deeper levels are smaller than / not
-    multiples of the 16x16 conv tiles, so the partial-tile paths of every conv kernel run.  Forward, losses and
+    multiples of the 16x16 conv tiles, so the partial-tile paths of every conv kernel run; 40 x 72 and 24 x 24 are
+    multiples of 8 only (the reference's own constraint): partial tiles at level 0 too (thin convs, fused head / tail).  Forward, losses and
     gradients (at the masks the HIP forward took) against the oracle."""
     rs = np.random.RandomState(5)
     B, H, W = shape
