@@ -163,6 +163,12 @@ SIFSR_API int sifsr_sif_loss(int kind, const float* sr, const float* lst, const 
 SIFSR_API int sifsr_adam_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                               void* stream);
+/* The same update with the step count in device memory (int64, incremented by the call) and a 2-float device scratch for
+ * the bias-correction coefficients: nothing depends on a host value that changes per step, so a whole training step
+ * (forward, loss, backward, Adam) can be captured into a hipGraph and replayed. */
+SIFSR_API int sifsr_adam_flat_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, long long* step_dev, float* coef2,
+                                  float grad_scale, void* stream);
 
 /* ---- the step before the path and the metrics after it --------------------
  * sifsr_tiles_prepare: per tile, what dataset.py:134-142 / predict.py:84-100 do on the host: z-score of the

@@ -338,3 +338,12 @@ int sifsr_l4pool4(const float* x, float* out, int B, int H, int W, void* stream)
   if (!x || !out) return SIFSR_ERR_ARG;
   return launch_l4pool4(x, out, B, H, W, S(stream));
 }
+
+// hipGraph-capturable Adam: the step counter (int64) and the two bias-correction coefficients live in device memory
+int sifsr_adam_flat_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, long long* step_dev, float* coef2, float grad_scale,
+                        void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq) return SIFSR_ERR_ARG;
+  return launch_adam_flat_dev(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, coef2,
+                              grad_scale, S(stream));
+}

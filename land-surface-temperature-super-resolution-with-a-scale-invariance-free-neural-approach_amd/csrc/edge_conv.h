@@ -52,6 +52,9 @@ int launch_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, h
 int launch_adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, float grad_scale, hipStream_t s);
 
+int launch_adam_flat_dev(float* p, const float* g, float* m, float* v, int n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, long long* step_dev, float* coef2, float grad_scale, hipStream_t s);
+
 // ---- pipeline.hip ---- (input pipeline before the model, metrics after it: SURVEY.md §8 f2 / f1)
 int launch_tiles_prepare(const float* lst, const float* ndvi, float* x, int T, int tiles_x, int win, long long lst_step_y,
                          long long lst_step_x, int lst_row, long long ndvi_step_y, long long ndvi_step_x, int ndvi_row,

@@ -17,7 +17,7 @@ class FlatAdam(torch.optim.Optimizer):
     kernel, e.g. 1/world_size after a sum all-reduce.
     """
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         if len(self.param_groups) != 1:
@@ -26,6 +26,11 @@ class FlatAdam(torch.optim.Optimizer):
         self._step = 0
         self._m = None
         self._v = None
+        # capturable=True (as torch.optim.Adam's flag): the step count lives on the device, so step() can be part of a
+        # captured hipGraph (train.GraphedTrainStep); ``_step`` then mirrors it only when state_dict() is taken
+        self.capturable = bool(capturable)
+        self._step_dev = None
+        self._coef = None
 
     def _flat_views(self):
         ps = self.param_groups[0]["params"]
@@ -65,6 +70,14 @@ class FlatAdam(torch.optim.Optimizer):
         if self._m is None or self._m.device != flat_p.device:
             self._m = torch.zeros(n, dtype=torch.float32, device=flat_p.device)
             self._v = torch.zeros(n, dtype=torch.float32, device=flat_p.device)
+        if self.capturable:
+            if self._step_dev is None or self._step_dev.device != flat_p.device:
+                self._step_dev = torch.full((1,), self._step, dtype=torch.int64, device=flat_p.device)
+                self._coef = torch.zeros(2, dtype=torch.float32, device=flat_p.device)
+            _lib.call("sifsr_adam_flat_dev", flat_p, flat_g, self._m, self._v, n, float(g["lr"]), float(g["betas"][0]),
+                      float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step_dev, self._coef,
+                      float(self.grad_scale), _lib.stream_ptr(flat_p.device))
+            return loss
         self._step += 1
         _lib.call("sifsr_adam_flat", flat_p, flat_g, self._m, self._v, n, float(g["lr"]), float(g["betas"][0]),
                   float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step, float(self.grad_scale),
@@ -73,6 +86,8 @@ class FlatAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         sd = super().state_dict()
+        if self.capturable and self._step_dev is not None:
+            self._step = int(self._step_dev.item())
         sd["flat"] = {"step": self._step, "exp_avg": self._m, "exp_avg_sq": self._v}
         return sd
 
@@ -81,3 +96,4 @@ class FlatAdam(torch.optim.Optimizer):
         super().load_state_dict(sd)
         if flat is not None:
             self._step, self._m, self._v = flat["step"], flat["exp_avg"], flat["exp_avg_sq"]
+            self._step_dev = None

@@ -338,3 +338,76 @@ def test_other_patch_sizes(sifsr, shape):
     with torch.inference_mode():
         y = make_model(sifsr, sd).eval()(x.cuda())
     assert rel_err(y, y_ref) < TOL
+
+
+def test_graph_captured_training_forward_backward(sifsr):
+    """The training forward + SIF loss + backward enqueue kernels only (no allocation outside torch's graph pool, no
+    host sync inside the library), so the whole thing captures into a hipGraph and replays on new data with the
+    gradients of an eager run."""
+    torch.manual_seed(1)
+    m = sifsr.ModelB_2(2, [16, 32, 64, 128], "replicate", "ReLU", 1, 1).cuda().train()
+    B = 2
+    lst_s = torch.zeros(B, 1, 64, 64, device="cuda"); up_s = torch.zeros(B, 1, 256, 256, device="cuda"); nd_s = torch.zeros_like(up_s)
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        sr = m(torch.cat((up_s, nd_s), 1))
+        ds, pl, loss = sifsr.sif_loss("sr2", sr, lst_s, nd_s, MEAN, STD, 0.5, -0.25)
+        loss.backward()
+        return loss.detach(), m.flat_grad()
+
+    lst, lst_up, ndvi = O.synthetic_batch(7, B)
+    lst_s.copy_(lst); up_s.copy_(lst_up); nd_s.copy_(ndvi)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss_g, grad_g = step()
+    # new data, BN buffers reset to the pre-capture state, replay vs eager
+    lst2, lst_up2, ndvi2 = O.synthetic_batch(8, B)
+    lst_s.copy_(lst2); up_s.copy_(lst_up2); nd_s.copy_(ndvi2)
+    m.load_state_dict(sd0)
+    graph.replay()
+    torch.cuda.synchronize()
+    loss_r, grad_r = float(loss_g), grad_g.clone()
+    m.load_state_dict(sd0)
+    loss_e, grad_e = step()
+    torch.cuda.synchronize()
+    assert abs(loss_r - float(loss_e)) <= 1e-6 * abs(float(loss_e))
+    assert torch.equal(grad_r, grad_e)          # same kernels, same inputs: bit-identical
+
+
+def test_graphed_train_step_matches_eager(sifsr):
+    """train.GraphedTrainStep (cat + forward + loss + backward + Adam in one hipGraph, step count on the device) against
+    the eager train_step from the same initial state: 3 eager warm-up calls, capture on the 4th, replays after."""
+    stats = {"mean_lst": MEAN, "std_lst": STD}
+    B, lr = 2, 1e-3
+    batches = [tuple(t.cuda() for t in O.synthetic_batch(60 + i, B)) for i in range(7)]
+
+    def run(graphed):
+        torch.manual_seed(5)
+        m = sifsr.ModelB_2(2, [16, 32, 64, 128], "replicate", "ReLU", 1, 1).cuda()
+        opt = sifsr.FlatAdam(m.parameters(), lr=lr, capturable=graphed)
+        stepper = sifsr.train.GraphedTrainStep(m, opt, B, stats, 0.5, -0.25, "sr2") if graphed else None
+        losses = []
+        for lst, lst_up, ndvi in batches:
+            out = stepper(lst, lst_up, ndvi) if graphed else sifsr.train.train_step(m, opt, lst, lst_up, ndvi, stats, 0.5, -0.25, "sr2")
+            losses.append(float(out[2].detach()))
+        torch.cuda.synchronize()
+        if graphed:
+            assert stepper.graph is not None and opt.state_dict()["flat"]["step"] == len(batches)
+        return losses, torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu(), {k: v.cpu() for k, v in m.state_dict().items()}
+
+    l_e, p_e, sd_e = run(False)
+    l_g, p_g, sd_g = run(True)
+    assert np.allclose(l_g, l_e, rtol=1e-5)
+    assert (p_g - p_e).abs().max().item() <= 1e-6          # device pow() vs host pow() in the bias correction: <= 1 ulp of lr
+    for k in sd_e:
+        if "num_batches_tracked" in k:
+            assert int(sd_g[k]) == int(sd_e[k]) == len(batches)
