@@ -202,6 +202,13 @@ SIFSR_API size_t sifsr_fft2_attenuation_scratch_bytes(int B, int H, int W);
 SIFSR_API int sifsr_fft2_attenuation(const float* img, int B, int H, int W, void* scratch, size_t scratch_bytes, float* mag,
                                      float* spectrum, void* stream);
 
+/* ---- schedule knob -----------------------------------------------------------------------------
+ * sifsr_model_backward runs the 16 MFMA weight gradients on a second, lower-priority stream owned by the library
+ * (forked from / joined to `stream` with events, so the call is still stream-ordered and hipGraph-capturable).
+ * on = 0 keeps everything on `stream`; on = 1 forces the second stream; -1 restores the default (environment variable
+ * SIFSR_WGRAD_STREAM, else on).  The results are bit-identical either way.  No reference counterpart. */
+SIFSR_API int sifsr_set_wgrad_stream(int on);
+
 /* ---- measurement hook (bench.py roofline) ------------------------------------------------------
  * Time ONE kernel of the model schedule with HIP events on its launch stream, inside normal steps:
  * layer = row of sifsr_layer_table, phase 1 = forward conv, 2 = dgrad, 3 = wgrad; layer < 0 disables.

@@ -291,6 +291,7 @@ int sifsr_adam_flat(float* params, const float* grads, float* exp_avg, float* ex
   return launch_adam_flat(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, S(stream));
 }
 
+int sifsr_set_wgrad_stream(int on) { return sifsr_engine_set_wgrad_stream(on); }
 int sifsr_profile_select(int layer, int phase) { return sifsr_engine_profile_select(layer, phase); }
 int sifsr_profile_read(float* total_ms, int* count) { return sifsr_engine_profile_read(total_ms, count); }
 

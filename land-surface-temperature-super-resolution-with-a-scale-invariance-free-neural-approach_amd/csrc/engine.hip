@@ -165,9 +165,11 @@ struct SideLane {
   bool ok = false;
 };
 
+int g_side_override = -1;   // sifsr_engine_set_wgrad_stream: -1 = environment default
+
 SideLane* side_lane() {
-  static const int enabled = getenv("SIFSR_WGRAD_STREAM") ? atoi(getenv("SIFSR_WGRAD_STREAM")) : 1;   // 0: single stream
-  if (!enabled) return nullptr;
+  static const int env_default = getenv("SIFSR_WGRAD_STREAM") ? atoi(getenv("SIFSR_WGRAD_STREAM")) : 1;   // 0: single stream
+  if (!(g_side_override >= 0 ? g_side_override : env_default)) return nullptr;
   static std::mutex mu;
   static SideLane lanes[16];
   static bool tried[16] = {};
@@ -530,6 +532,11 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
 // ---------------------------------------------------------------------------------------------
 // profiling hooks
 // ---------------------------------------------------------------------------------------------
+int sifsr_engine_set_wgrad_stream(int on) {
+  g_side_override = on < 0 ? -1 : (on ? 1 : 0);
+  return SIFSR_OK;
+}
+
 int sifsr_engine_profile_select(int layer, int phase) {
   for (size_t i = 0; i < g_prof.start.size(); ++i) { (void)hipEventDestroy(g_prof.start[i]); (void)hipEventDestroy(g_prof.stop[i]); }
   g_prof.start.clear(); g_prof.stop.clear();

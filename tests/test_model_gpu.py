@@ -411,3 +411,26 @@ def test_graphed_train_step_matches_eager(sifsr):
     for k in sd_e:
         if "num_batches_tracked" in k:
             assert int(sd_g[k]) == int(sd_e[k]) == len(batches)
+
+
+def test_wgrad_stream_on_off_bit_identical(sifsr):
+    """The weight gradients run on the library's second stream by default (engine.hip SideLane); forcing the single
+    stream must give bit-identical gradients and loss -- same kernels, same inputs, only the interleaving differs."""
+    from sifsr import _lib
+    lst, lst_up, ndvi = (t.cuda() for t in O.synthetic_batch(21, 3))
+    out = []
+    try:
+        for on in (1, 0, 1):
+            _lib.call("sifsr_set_wgrad_stream", on)
+            torch.manual_seed(9)
+            m = sifsr.ModelB_2(2, [16, 32, 64, 128], "replicate", "ReLU", 1, 1).cuda().train()
+            sr = m(torch.cat((lst_up, ndvi), 1))
+            ds, pl, loss = sifsr.sif_loss("sr2", sr, lst, ndvi, MEAN, STD, 0.5, -0.25)
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append((float(loss.detach()), m.flat_grad().clone()))
+    finally:
+        _lib.call("sifsr_set_wgrad_stream", -1)
+    assert out[0][0] == out[1][0] == out[2][0]
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][1], out[2][1])
+    assert out[0][1].abs().max().item() > 0
