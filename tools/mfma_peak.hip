@@ -21,10 +21,9 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int i = 0; i < 8; ++i) a[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[(i + r) & 7], y[(i + 3 * r) & 7], a[i], 0, 0, 0);
-    if (RANDOM) {   // keep the accumulators bounded without touching the issue pattern much
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] *= 0.5f;
-    }
+    // no rescaling of the accumulators: with |x|, |y| < 1 they random-walk to ~1e3 over a launch, far from overflow,
+    // and any VALU instruction in this loop would serialise with the MFMAs (tools/mfma_valu_coexec.hip) and read as
+    // a lower "peak" (an earlier version scaled them by 0.5 per iteration and measured 141 TFLOP/s for that reason)
   }
   float sum = 0.f;
   for (int i = 0; i < 8; ++i) sum += a[i][0] + a[i][1] + a[i][2] + a[i][3];
