@@ -249,6 +249,22 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
     const int t_next = t + t_step;
     const bool more = !last_q || t_next < t_hi;
 
+    // fused BatchNorm-backward sums (NB == 1 dgrad): y of the previous layer for this tile's 4 rows per wave is
+    // requested BEFORE the MFMA loop of the tile's last channel block and consumed in the epilogue, so the epilogue
+    // does not park the wave on a fresh HBM round trip (SQ_WAIT_ANY 0.44 -> see DESIGN.md section 10)
+    float4 yq[NB == 1 ? 4 : 1];
+    float4 bsc = make_float4(0.f, 0.f, 0.f, 0.f), bsh = bsc;
+    if (NB == 1 && bn_stats && last_q) {
+      int cb_, txi_, tyi_;
+      tile_pos(t, cb_, txi_, tyi_);
+      const unsigned tp_ = (unsigned)((cb_ * H + tyi_ * 16 + g0) * W + txi_ * 16);
+      const bool colok_ = txi_ * 16 + px < W;
+      const int rows_ok_ = H - (tyi_ * 16 + g0);
+      bsc = ld4(a.bn_scale + 4 * kq); bsh = ld4(a.bn_shift + 4 * kq);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        yq[g] = bload4(rby, (colok_ && g < rows_ok_) ? (unsigned)px * 64u + (unsigned)kq * 16u : OOB, (tp_ + (unsigned)(g * W)) * 64u);
+    }
     const float4* L = lds[buf];
     // The weights of the NEXT item (channel block q+1, or block 0 of the next tile; NQ == 1: the same ones again) are
     // fetched tap by tap as soon as the current tap's MFMAs are issued (tap-outer loop order), so their L2 latency hides
@@ -336,16 +352,6 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
     const bool colok = txi * 16 + px < W;
     const int rows_ok = H - (tyi * 16 + g0);
     const bool do_stats = a.stat_partials != nullptr && !bn_stats;
-    // y of the previous layer for this tile's rows (NB == 1: 4 rows per wave): issued first, consumed after the stores
-    // (prefetching them across the MFMA loop costs 16 live registers: spills at the 128-VGPR budget)
-    float4 yq[NB == 1 ? 4 : 1];
-    float4 bsc = make_float4(0.f, 0.f, 0.f, 0.f), bsh = bsc;
-    if (NB == 1 && bn_stats) {
-      bsc = ld4(a.bn_scale + 4 * kq); bsh = ld4(a.bn_shift + 4 * kq);   // reloaded per tile (L2 hits): not worth 8 live VGPRs
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        yq[g] = bload4(rby, (colok && g < rows_ok) ? (unsigned)px * 64u + (unsigned)kq * 16u : OOB, (tile_pix + (unsigned)(g * W)) * 64u);
-    }
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
       const int nb = nb0 + 4 * c;
