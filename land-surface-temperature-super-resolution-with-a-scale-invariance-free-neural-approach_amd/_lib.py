@@ -15,7 +15,8 @@ import torch  # noqa: F401  (must be imported first: the library binds to the li
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "sifsr_hip.h")
-LIB_PATH = os.path.join(_HERE, "libsifsr_hip.so")
+# SIFSR_LIB: another build of the same C ABI (same-device A/B of kernel variants, tools/ab/); default: the in-tree library
+LIB_PATH = os.environ.get("SIFSR_LIB") or os.path.join(_HERE, "libsifsr_hip.so")
 
 _CTYPES = {
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,

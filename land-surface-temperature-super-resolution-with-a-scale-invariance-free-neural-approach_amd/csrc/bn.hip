@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, size_t npix,
                                                             float* __restrict__ partials, const PoolAdj pa) {
+  SIFSR_CHAIN_PRIO();
   constexpr int Q = C / 4;          // channel quads
   constexpr int PP = 256 / Q;       // pixels per pass per workgroup
   __shared__ double red[256][8];   // float64 accumulation: dy = scale*(dz - mean(dz) - ...) cancels heavily
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* dgamma,
                                                               float* dbeta, double* coef) {
+  SIFSR_CHAIN_PRIO();
   __shared__ double r1[256], r2[256];
   const int c = blockIdx.x, tid = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __re
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, float* dgamma,
                                                                float* dbeta, double* coef) {
+  SIFSR_CHAIN_PRIO();
   __shared__ double r1[256], r2[256];
   const int c = blockIdx.x, tid = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ shift,
                                                            const double* __restrict__ coef,
                                                            size_t nquads, float* __restrict__ dy, const PoolAdj pa) {
+  SIFSR_CHAIN_PRIO();
   constexpr int Q = C / 4;
   const int c4 = threadIdx.x % Q;   // 256 % Q == 0 and grid stride is a multiple of 256
   const float4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4);

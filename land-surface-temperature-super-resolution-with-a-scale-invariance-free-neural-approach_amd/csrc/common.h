@@ -15,6 +15,11 @@
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// Kernels on the serial chain of the backward pass raise their waves' instruction-issue priority: a weight-gradient
+// kernel of the previous layer may be running beside them on the library's second stream (engine.hip SideLane) at the
+// default priority 0, and whatever it delays here delays the whole chain.  No effect when nothing runs beside them.
+#define SIFSR_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
+
 #define SIFSR_LAUNCH_CHECK()                         \
   do {                                               \
     hipError_t e__ = hipGetLastError();              \

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restr
                                                             const float* __restrict__ shift,
                                                             const double* __restrict__ coef,
                                                             float* __restrict__ partials, int B, int H, int W) {
+  SIFSR_CHAIN_PRIO();
   __shared__ float tile[2 * 324 + 8];
   __shared__ float dyt[256 * 16];
   __shared__ float red[4][2][256];

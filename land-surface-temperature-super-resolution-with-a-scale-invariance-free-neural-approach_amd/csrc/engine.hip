@@ -155,9 +155,11 @@ ConvSrc src_none() { ConvSrc s; s.ptr = nullptr; s.scale = nullptr; s.shift = nu
 //   main:  ... bn_bwd(l) --record ev[l]--> dgrad(l) -> bn_bwd(l-1) ...            -> wait(join) -> slab reduce
 //   side:                  wait ev[l] -> wgrad(l)            ... -> record join
 // Fork / join by events only, so the pair of streams is still capturable into one hipGraph.  Measured (B = 64):
-// 8.52 -> 8.40 ms per step; the gain is small because the chain's dgrad already fills the register file of every CU
-// (co-resident wgrad waves slow it down by what they gain) -- only the BatchNorm / adjoint kernels overlap for free.
-// Issuing wgrad(l) behind dgrad(l) instead of beside it was worse (8.57 ms).  SIFSR_WGRAD_STREAM=0 disables it.
+// 8.52 -> 8.40 ms per step, and -> 8.0 ms once the chain's kernels raise their wave priority (SIFSR_CHAIN_PRIO, common.h):
+// without it the small latency-bound kernels of the chain (border fold, BatchNorm finalize) ran 5-10x slower beside a
+// weight-gradient kernel than alone.  Issuing wgrad(l) behind dgrad(l) instead of beside it was worse (8.57 ms), and
+// so was running the border fold beside the main dgrad kernel on a third stream (two more event hand-offs per layer).
+// SIFSR_WGRAD_STREAM=0 / sifsr_set_wgrad_stream(0) disables the second stream.
 struct SideLane {
   hipStream_t s = nullptr;
   hipEvent_t ev[SIFSR_NUM_BN_LAYERS] = {};

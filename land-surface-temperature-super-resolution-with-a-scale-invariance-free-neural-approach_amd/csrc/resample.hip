@@ -102,6 +102,7 @@ __global__ void pool2_bwd_kernel(const float* __restrict__ gp, float* __restrict
 // high-res pixels whose two source taps include it (output rows 2i-2 .. 2i+2 are the only candidates
 // because ratio < 1/2).
 __global__ void up2x_bwd_kernel(const float* __restrict__ gu, float* __restrict__ g, int B, int Hin, int Win, int C) {
+  SIFSR_CHAIN_PRIO();
   const int Q = C / 4, Ho = 2 * Hin, Wo = 2 * Win;
   const size_t n = (size_t)B * Hin * Win * Q;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256) void bnrelu_up2x_tile_kernel(const float* __re
 template <int C>
 __global__ __launch_bounds__(256) void up2x_bwd_tile_kernel(const float* __restrict__ gu, float* __restrict__ g, int Hin,
                                                             int Win) {
+  SIFSR_CHAIN_PRIO();
   constexpr int TL = 8, HR = 2 * TL + 3, NCH = C / 16;
   __shared__ float4 hi[HR * HR * 4];
   __shared__ float4 tmp[HR * TL * 4];
