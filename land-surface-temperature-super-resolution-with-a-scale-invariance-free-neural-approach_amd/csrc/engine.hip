@@ -154,7 +154,7 @@ ConvSrc src_none() { ConvSrc s; s.ptr = nullptr; s.scale = nullptr; s.shift = nu
 // lower-priority stream and fill the matrix cores while the chain's memory-bound kernels stream:
 //   main:  ... bn_bwd(l) --record ev[l]--> dgrad(l) -> bn_bwd(l-1) ...            -> wait(join) -> slab reduce
 //   side:                  wait ev[l] -> wgrad(l)            ... -> record join
-// Fork / join by events only, so the pair of streams is still capturable into one hipGraph.  Measured (B = 64):
+// Fork / join by events only.  Measured (B = 64):
 // 8.52 -> 8.40 ms per step, and -> 8.0 ms once the chain's kernels raise their wave priority (SIFSR_CHAIN_PRIO, common.h):
 // without it the small latency-bound kernels of the chain (border fold, BatchNorm finalize) ran 5-10x slower beside a
 // weight-gradient kernel than alone.  Issuing wgrad(l) behind dgrad(l) instead of beside it was worse (8.57 ms), and
@@ -169,7 +169,7 @@ struct SideLane {
 
 int g_side_override = -1;   // sifsr_engine_set_wgrad_stream: -1 = environment default
 
-SideLane* side_lane() {
+SideLane* side_lane(hipStream_t main_stream) {
   static const int env_default = getenv("SIFSR_WGRAD_STREAM") ? atoi(getenv("SIFSR_WGRAD_STREAM")) : 1;   // 0: single stream
   if (!(g_side_override >= 0 ? g_side_override : env_default)) return nullptr;
   static std::mutex mu;
@@ -177,6 +177,16 @@ SideLane* side_lane() {
   static bool tried[16] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  // Under stream capture the backward stays on the one stream: the fork/join would be legal, but hipGraph replay of the
+  // resulting two-branch graph is slow on ROCm 7.2 (measured 11.6 ms per step against 8.5 ms for the linear graph and
+  // 8.0 ms for eager two-stream execution at batch 64).
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(main_stream, &cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (cap != hipStreamCaptureStatusNone) return nullptr;
+  if (main_stream != nullptr) {   // the caller's stream must live on the calling thread's device (the lane is per device)
+    hipDevice_t sdev = -1;
+    if (hipStreamGetDevice(main_stream, &sdev) != hipSuccess || (int)sdev != dev) { (void)hipGetLastError(); return nullptr; }
+  }
   std::lock_guard<std::mutex> lk(mu);
   SideLane& L = lanes[dev];
   if (!tried[dev]) {
@@ -431,7 +441,9 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   WgradReduceJob jobs[16];
   int njobs = 0;
   c.jobs = jobs; c.njobs = &njobs;
-  c.side = side_lane();
+  // tiny problems are launch-latency-bound: the 17 event hand-offs cost more than the overlap returns (batch 1 at 256x256:
+  // 1.67 ms with the second stream, 1.56 without; batch 4: 1.72 against 1.81)
+  c.side = (size_t)B * H * W >= 2u * 65536u || g_side_override == 1 ? side_lane(s) : nullptr;
 
   // outlay backward fused with the BatchNorm+ReLU backward of ub3.convbloc.bloc.3 (fused_edges.hip): the outlay
   // input gradient is recomputed from dsr in both passes instead of being stored; dy(L_U3B) -> g[L_U3B]
