@@ -176,12 +176,17 @@ class _SifLoss(torch.autograd.Function):
         ctx.dsr = dsr
         ds, pl, loss = losses[0], losses[1], losses[2]
         ctx.mark_non_differentiable(ds, pl)
+        ctx.set_materialize_grads(False)     # no zero-filled gradients for ds / pl (two fill launches per step)
         return ds, pl, loss
 
     @staticmethod
     def backward(ctx, g_ds, g_pl, g_loss):
         dsr = ctx.dsr
         ctx.dsr = None
+        if g_loss is None:                   # only ds / pl were used downstream: they carry no gradient
+            return (None,) * 8
+        if dsr is None:
+            raise _lib.SifsrError("sif_loss: backward called twice (d loss / d sr was released after the first call)")
         return dsr * g_loss, None, None, None, None, None, None, None
 
 
