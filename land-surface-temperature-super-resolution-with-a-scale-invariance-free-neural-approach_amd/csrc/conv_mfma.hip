@@ -483,7 +483,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
 //   corners belong to the top/bottom passes and add, on the corner lane only,
 //     top-left: ((0,-1),(0,0)), ((-1,-1),(1,0)+(0,0))      top-right: ((0,+1),(0,W-1)), ((-1,+1),(1,W-1)+(0,W-1))
 //     bottom-left: ((0,-1),(H-1,0)), ((+1,-1),(H-2,0)+(H-1,0))   bottom-right: mirrored.
-__global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restrict__ dy, int Cout,
+__global__ __launch_bounds__(256, 8) void dgrad_border_kernel(const float* __restrict__ dy, int Cout,
                                                            const float* __restrict__ wd, int Cin, float* g0, int C0,
                                                            int split_ch, float* g1, int C1, int B, int H, int W,
                                                            int bf16, const float* __restrict__ bn_y,
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
                                                            const float* __restrict__ bn_shift,
                                                            float* __restrict__ bn_partials) {
   const int lane = threadIdx.x & 63;
-  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int NBI = Cin / 16, NQ = Cout / 16;
   const int seg_tb = (W + 15) / 16, seg_lr = (H - 2 + 15) / 16;
   const int per_img = (2 * seg_tb + 2 * seg_lr) * NBI;
@@ -525,39 +525,34 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
   else { qx = side == 2 ? 0 : W - 1; qy = 1 + seg * 16 + px; valid = qy <= H - 2; }
   // The kernel runs beside a weight-gradient kernel that keeps the HBM queues full, so every dependent round trip
   // costs several microseconds.  Everything is therefore requested up front and branch-free: the read-modify-write
-  // operand and the BatchNorm operands here, and per pair of channel blocks ALL dy rows (buffer loads; masked lanes
-  // take the out-of-range offset and read 0) and weights before the first MFMA.
+  // operand here, and per channel block all dy rows (buffer loads; masked lanes take the out-of-range offset and
+  // read 0) and weights before the first MFMA.
   const size_t pix_o = valid ? (size_t)(b * H + qy) * W + qx : 0;
   const int ci_o = 16 * nb + 4 * kq;
   float* const dst = ci_o < split_ch ? g0 + pix_o * C0 + ci_o : g1 + pix_o * C1 + (ci_o - split_ch);
   const float4 g_old = valid ? ld4(dst) : z4;
-  float4 yv = z4, bsc = z4, bsh = z4;
-  if (bn_partials != nullptr && valid) { yv = ld4(bn_y + pix_o * 16 + 4 * kq); bsc = ld4(bn_scale + 4 * kq); bsh = ld4(bn_shift + 4 * kq); }
 
   const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (unsigned)B * (unsigned)H * (unsigned)W * (unsigned)Cout * 4u);
   auto poff = [&](int y, int x, bool ok) {
     return ok ? (unsigned)((b * H + y) * W + x) * (unsigned)Cout * 4u + (unsigned)kq * 16u : OOB;
   };
-  // sources 0..2: the three taps every border pixel has; 3..6: corner lanes (top/bottom passes, first/last segment):
-  //   3 = e_left, 4 = n_left, 5 = e_right, 6 = n_right with e = the corner pixel, n = its vertical neighbour;
-  //   weights 3/4 = taps (0,-1), (ty,-1); 5/6 = taps (0,+1), (ty,+1); the (ty,+-1) tap multiplies e + n.
-  unsigned ro[7];
-  int wt[7];
+  // ro / wt: the three taps every border pixel has.  Corner lanes (top/bottom passes, first/last segment) add
+  //   e_left, n_left, e_right, n_right with e = the corner pixel, n = its vertical neighbour, under the taps
+  //   (0,-1), (ty,-1) / (0,+1), (ty,+1); the (ty,+-1) tap multiplies e + n.  Their offsets are formed where they are
+  //   used (registers, see below).
+  unsigned ro[3];
+  int wt[3];
   bool cl = false, cr = false;
+  const int ty_tb = side == 0 ? -1 : 1;                    // top / bottom passes
+  const int yin = side == 0 ? 1 : H - 2;                   // the row next to the border row
   if (side < 2) {
-    const int ty = side == 0 ? -1 : 1;
-    const int yin = side == 0 ? 1 : H - 2;                  // the row next to the border row
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int tx = i - 1, sx = qx - tx;
       ro[i] = poff(qy, sx < 0 ? 0 : (sx >= W ? W - 1 : sx), valid && sx >= 0 && sx < W);
-      wt[i] = 8 - ((ty + 1) * 3 + (tx + 1));
+      wt[i] = 8 - ((ty_tb + 1) * 3 + (tx + 1));
     }
     cl = seg == 0; cr = seg == seg_tb - 1;
-    ro[3] = poff(qy, 0, cl && valid && qx == 0);         ro[4] = poff(yin, 0, cl && valid && qx == 0);
-    ro[5] = poff(qy, W - 1, cr && valid && qx == W - 1); ro[6] = poff(yin, W - 1, cr && valid && qx == W - 1);
-    wt[3] = 8 - (1 * 3 + 0); wt[4] = 8 - ((ty + 1) * 3 + 0);
-    wt[5] = 8 - (1 * 3 + 2); wt[6] = 8 - ((ty + 1) * 3 + 2);
   } else {
     const int tx = side == 2 ? -1 : 1;
     const int yc = valid ? qy : H - 2;
@@ -567,39 +562,33 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
       ro[i] = poff(yc - ty, qx, valid);
       wt[i] = 8 - ((ty + 1) * 3 + (tx + 1));
     }
-#pragma unroll
-    for (int i = 3; i < 7; ++i) { ro[i] = OOB; wt[i] = 0; }
   }
   const bool corner = cl || cr;                            // wave-uniform
-  constexpr int QC = 1;
-  for (int q0 = 0; q0 < NQ; q0 += QC) {
-    float4 rv[QC][7], wv[QC][7];
+  // Register budget <= 64: beside a resident weight-gradient kernel (96 registers x 4 waves per SIMD) only 128
+  // registers per SIMD are free, so the number of border waves in flight -- and with it this kernel's duration on the
+  // serial chain -- is set by its register count (measured beside wgrad<1,1>: 155 VGPRs 70-120 us, 99 VGPRs 25-30 us).
+  // Hence one channel block at a time, and the corner sources reuse the registers of the three main taps.
+  for (int q = 0; q < NQ; ++q) {
+    float4 rv[3], wv[3];
 #pragma unroll
-    for (int j = 0; j < QC; ++j) {
-      const bool on = q0 + j < NQ;                         // NQ == 1: the second slot reads zeros
-      const int q = on ? q0 + j : NQ - 1;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        rv[j][i] = bload4(rdy, on ? ro[i] : OOB, (unsigned)q * 64u);
-        wv[j][i] = ld4(wbase + ((size_t)q * 9 + wt[i]) * 256);
-      }
-      if (corner) {
-#pragma unroll
-        for (int i = 3; i < 7; ++i) {
-          rv[j][i] = bload4(rdy, on ? ro[i] : OOB, (unsigned)q * 64u);
-          wv[j][i] = ld4(wbase + ((size_t)q * 9 + wt[i]) * 256);
-        }
-      }
+    for (int i = 0; i < 3; ++i) {
+      rv[i] = bload4(rdy, ro[i], (unsigned)q * 64u);
+      wv[i] = ld4(wbase + ((size_t)q * 9 + wt[i]) * 256);
     }
 #pragma unroll
-    for (int j = 0; j < QC; ++j) {
+    for (int i = 0; i < 3; ++i) mac(wv[i], rv[i], true);
+    if (corner) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) mac(wv[j][i], rv[j][i], true);
-      if (corner) {
-        float4 e0 = rv[j][3], n0 = rv[j][4], e1 = rv[j][5], n1 = rv[j][6];
-        if (bf16) { e0 = round_bf16x4(e0); n0 = round_bf16x4(n0); e1 = round_bf16x4(e1); n1 = round_bf16x4(n1); }
-        mac(wv[j][3], e0, false); mac(wv[j][4], add4(e0, n0), false);
-        mac(wv[j][5], e1, false); mac(wv[j][6], add4(e1, n1), false);
+      for (int sd = 0; sd < 2; ++sd) {                       // left corner, then right corner
+        const int xc = sd == 0 ? 0 : W - 1;
+        const bool on = (sd == 0 ? cl : cr) && valid && qx == xc;
+        rv[0] = bload4(rdy, poff(qy, xc, on), (unsigned)q * 64u);
+        rv[1] = bload4(rdy, poff(yin, xc, on), (unsigned)q * 64u);
+        wv[0] = ld4(wbase + ((size_t)q * 9 + (8 - (1 * 3 + 2 * sd))) * 256);
+        wv[1] = ld4(wbase + ((size_t)q * 9 + (8 - ((ty_tb + 1) * 3 + 2 * sd))) * 256);
+        if (bf16) { rv[0] = round_bf16x4(rv[0]); rv[1] = round_bf16x4(rv[1]); }
+        mac(wv[0], rv[0], false);
+        mac(wv[1], add4(rv[0], rv[1]), false);
       }
     }
   }
@@ -613,7 +602,8 @@ __global__ __launch_bounds__(256) void dgrad_border_kernel(const float* __restri
     // the BatchNorm-backward sums are linear in g: this wave adds (delta*mask, delta*mask*y) of its 16 border pixels
     // for its 16 channels (Cin == 16 here, nb == 0); rows of bn_partials = global wave index
     float d1[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f};
-    if (valid) {
+    if (valid) {   // loaded here, not at the top: 12 live registers through the MFMA loop would break the 64-register budget
+      const float4 yv = ld4(bn_y + pix_o * 16 + 4 * kq), bsc = ld4(bn_scale + 4 * kq), bsh = ld4(bn_shift + 4 * kq);
       const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, scv[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, shv[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

@@ -55,6 +55,8 @@ static int wgrad_blocks(int cin, int cout, int chunks, int ntiles) {
   // persistent, software-pipelined workgroups: two per CU are resident (four for the 16->16 variant: 20 KB LDS,
   // 66 VGPRs), so launch that many in total (x-dim = total / Cin chunks in blockIdx.y), but keep >= 4 tiles per
   // workgroup so that the slab write + slab reduction stay small next to the MFMA work (measured per layer).
+  // (re-swept with the weight gradients on the second stream: smaller grids leave the chain more room but lose more
+  // than they give -- 1024 / 512 stay)
   const int total = (cin == 16 && cout == 16) ? 1024 : 512;
   int n = total / chunks;
   if (n < 64) n = 64;
