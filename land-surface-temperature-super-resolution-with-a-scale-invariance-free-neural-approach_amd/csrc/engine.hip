@@ -511,6 +511,10 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   // inbloc
   SIFSR_TRY(bn_unit_bwd(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN3]), grads, c.f(w.gP[0])));
   SIFSR_TRY(conv_unit_wgrad(c, L_IN3, src_act(c, L_IN0), src_none(), c.f(w.g[L_IN3]), grads));
+  // that was the last MFMA layer: all 16 layers' weight-gradient slabs -> OIHW gradients, one launch.  With the second
+  // stream it follows the last weight gradient there (it writes only the conv-weight regions of `grads`, which nothing
+  // on the caller's stream touches) and overlaps the head of the chain instead of trailing it.
+  if (c.side != nullptr) SIFSR_TRY(launch_wgrad_reduce_batched(ws, jobs, njobs, grads, c.side->s));
   int rows_in0 = 0;
   SIFSR_TRY(conv_unit_dgrad(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), 16, 16, nullptr, 0, nullptr, L_IN0, &rows_in0));
   // first layer: no input gradient, so dy(L_IN0) is consumed by the weight gradient alone and is formed on the
@@ -536,12 +540,12 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
                                          reinterpret_cast<const double*>(c.f(w.coef)), c.f(w.slabs), nblk,
                                          grads + L.w_off, B, H, W, s));
   }
-  // all 16 MFMA layers' weight-gradient slabs -> OIHW gradients, one launch
-  if (c.side != nullptr) {
+  if (c.side != nullptr) {   // hand the second stream's work back to the caller's stream
     if (hipEventRecord(c.side->join, c.side->s) != hipSuccess || hipStreamWaitEvent(s, c.side->join, 0) != hipSuccess)
       return SIFSR_ERR_ARG;
+  } else {
+    SIFSR_TRY(launch_wgrad_reduce_batched(ws, jobs, njobs, grads, s));
   }
-  SIFSR_TRY(launch_wgrad_reduce_batched(ws, jobs, njobs, grads, s));
   return SIFSR_OK;
 }
 
