@@ -138,21 +138,23 @@ def test_conv3x3_fwd_dgrad_wgrad(L, case):
         assert rel_err(dwo.cpu(), gw_ref) < TOL, nb
 
 
-def test_conv_in(L):
+@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 24, 40), (2, 40, 24)])   # full and partial 16x16 tiles
+def test_conv_in(L, shape):
     rs = np.random.RandomState(1)
-    B, H, W = 2, 32, 48
+    B, H, W = shape
     x = rnd(rs, B, 2, H, W)
     w = rnd(rs, 16, 2, 3, 3, scale=0.3).requires_grad_(True)
     y_ref = conv_rep(x, w)
     dy = rnd(rs, B, 16, H, W)
     (gw_ref,) = torch.autograd.grad((y_ref * dy).sum(), [w])
     y = torch.empty(B, H, W, 16, device="cuda")
-    nblk = B * (H // 16) * (W // 16)
+    nblk = B * ((H + 15) // 16) * ((W + 15) // 16)
     part = torch.empty(nblk, 16, 2, device="cuda")
     L.call("sifsr_conv_in_fwd", dev(x), dev(w.detach()), y, part, B, H, W, S())
     torch.cuda.synchronize()
     assert rel_err(nchw(y.cpu()), y_ref) < TOL
     assert torch.allclose(part.cpu().double().sum(0)[:, 0], y_ref.detach().double().sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(part.cpu().double().sum(0)[:, 1], (y_ref.detach().double() ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
     scratch = torch.empty(8 * 288, device="cuda")
     dw = torch.empty(16, 2, 3, 3, device="cuda")
     L.call("sifsr_conv_in_wgrad", dev(x), dev(nhwc(dy)), scratch, 5, dw, B, H, W, S())
@@ -160,9 +162,10 @@ def test_conv_in(L):
     assert rel_err(dw.cpu(), gw_ref) < TOL
 
 
-def test_conv_out(L):
+@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 24, 40), (2, 40, 24)])
+def test_conv_out(L, shape):
     rs = np.random.RandomState(2)
-    B, H, W = 2, 32, 48
+    B, H, W = shape
     yraw = rnd(rs, B, 16, H, W)
     sc = torch.from_numpy(rs.uniform(0.5, 1.5, 16).astype(np.float32)); sh = rnd(rs, 16, scale=0.3)
     a = F.relu(yraw * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
