@@ -89,9 +89,11 @@ def main():
     ap.add_argument("--kind", default="sr2", choices=["sr2", "sr1"])
     ap.add_argument("--roofline-kernel", default="fwd_16x16_256", choices=sorted(ROOFLINE_KERNELS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16x3"],
                     help="f32 = the headline fp32 path; bf16 = BASELINE.json config 5 (bf16 MFMA operands in the 3x3 conv "
-                         "forward / input-gradient / weight-gradient passes, fp32 accumulation and storage) -- never the default")
+                         "forward / input-gradient / weight-gradient passes, fp32 accumulation and storage); bf16x3 = fp32 on the bf16 "
+                         "matrix cores (exact three-way bf16 split of every conv operand, six cross products; fp32-level results) "
+                         "-- neither is the default")
     args = ap.parse_args()
 
     import sifsr
@@ -111,7 +113,7 @@ def main():
     stats = dict(sifsr.dataset.DEFAULT_STATS)
     torch.manual_seed(0)
     model = sifsr.ModelB_2(2, [16, 32, 64, 128], "replicate", "ReLU", 1, 1).to(dev)
-    model.compute_dtype = "bf16" if args.dtype == "bf16" else "fp32"
+    model.compute_dtype = {"f32": "fp32", "bf16": "bf16", "bf16x3": "bf16x3"}[args.dtype]
     opt = sifsr.FlatAdam(model.parameters(), lr=lr)
     lst, lst_up, ndvi = sifsr.dataset.synthetic_device_batch(args.batch, dev, seed=1234 + rank)
 
@@ -153,7 +155,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000 * dt / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "f32" else "bf16 conv operands (fwd, dgrad, wgrad), f32 accumulate/storage", "data": "synthetic",
+        "dtype": {"f32": "f32", "bf16": "bf16 conv operands (fwd, dgrad, wgrad), f32 accumulate/storage",
+                  "bf16x3": "f32 as 3-term bf16 splits (conv fwd, dgrad: 6 bf16 MFMA cross products), f32 accumulate/storage; wgrad f32 MFMA"}[args.dtype],
+        "data": "synthetic",
         "config": {"workload": f"ModelB SIF-NN-{kind.upper()} ({'gradFTM' if kind == 'sr2' else 'predef_filters'} loss) "
                                f"batch {args.batch}/GPU, synthetic 256x256, {world}x MI355X, fwd+loss+bwd+Adam",
                    "batch_per_gpu": args.batch, "patch": "256x256 (LST 64x64 + NDVI 256x256)",

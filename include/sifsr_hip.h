@@ -62,8 +62,9 @@ SIFSR_API int sifsr_model_backward_ex(const float* x, const float* dsr, const fl
                                       size_t workspace_bytes, int B, int H, int W, int compute, void* stream);
 
 /* ---- 3x3 convolution pieces (nn.Conv2d(k=3,padding=1,padding_mode='replicate'), model.py:135,138,507) */
-/* OIHW -> MFMA fragment order: wfwd 9*cin*cout floats (forward operand); wdgrad 2*9*cin*cout floats
- * (transposed+flipped dgrad operand followed by a tap-major copy for the replicate-border fold) */
+/* OIHW -> MFMA fragment order: wfwd 9*cin*cout floats (forward operand); wdgrad 4*9*cin*cout floats: the
+ * transposed+flipped fp32 dgrad operand (n = 9*cin*cout floats) followed by six bf16 packs of n/2 floats each,
+ * [fwd hi | dgrad hi | fwd mid | dgrad mid | fwd lo | dgrad lo], with hi + mid + lo = w exactly (hi = bf16(w)). */
 SIFSR_API int sifsr_pack_conv_weights(const float* w_oihw, int cin, int cout, float* wfwd, float* wdgrad, void* stream);
 /* y = conv(cat([a0, a1], C)), a_i = relu(src_i*scale_i+shift_i) if scale_i != NULL else src_i (NHWC, C_i % 16 == 0;
  * src1 may be NULL).  stat_partials: NULL or [sifsr_conv3x3_stat_blocks()][cout][2] per-workgroup (sum, sumsq) of y. */
@@ -85,6 +86,15 @@ SIFSR_API int sifsr_conv3x3_fwd_bf16(const float* src0, int C0, const float* sca
                                      int cout, float* stat_partials, int B, int H, int W, void* stream);
 SIFSR_API int sifsr_conv3x3_dgrad_bf16(const float* dy, int cout, const float* wdgrad, int cin, float* g0, int C0, float* g1,
                                        int C1, const float* addend, int B, int H, int W, void* stream);
+/* split-bf16 forms ("fp32 on the bf16 matrix cores", compute mode 2 of sifsr_model_*_ex): activations and weights are
+ * split exactly into three bf16 terms while staging (x = hi + mid + lo) and six of the nine cross products are
+ * accumulated in fp32 (the dropped ones are <= 2^-24 relative): six v_mfma_f32_16x16x16_bf16 per 16 channels instead
+ * of four v_mfma_f32_16x16x4_f32 at a quarter of the cycles each.  Results agree with the fp32 forms to fp32 rounding. */
+SIFSR_API int sifsr_conv3x3_fwd_bf16x3(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1,
+                                       int C1, const float* scale1, const float* shift1, const float* wdgrad, float* y,
+                                       int cout, float* stat_partials, int B, int H, int W, void* stream);
+SIFSR_API int sifsr_conv3x3_dgrad_bf16x3(const float* dy, int cout, const float* wdgrad, int cin, float* g0, int C0, float* g1,
+                                         int C1, const float* addend, int B, int H, int W, void* stream);
 SIFSR_API size_t sifsr_conv3x3_wgrad_scratch_floats(int cin, int cout, int nblk);
 /* dw (OIHW) = sum_pixels dy (x) a_in; deterministic 2-stage reduction through `scratch`. */
 SIFSR_API int sifsr_conv3x3_wgrad(const float* src0, int C0, const float* scale0, const float* shift0,

@@ -57,13 +57,13 @@ int sifsr_model_backward(const float* x, const float* dsr, const float* params, 
 int sifsr_model_forward_ex(const float* x, float* sr, const float* params, float* running, long long* nbt, void* workspace,
                            size_t workspace_bytes, int B, int H, int W, int training, float momentum, float eps, int compute,
                            void* stream) {
-  if (compute != 0 && compute != 1) return SIFSR_ERR_ARG;
+  if (compute < 0 || compute > 2) return SIFSR_ERR_ARG;
   return sifsr_engine_forward(x, sr, params, running, nbt, (float*)workspace, workspace_bytes / sizeof(float), B, H, W,
                               training, momentum, eps, S(stream), compute);
 }
 int sifsr_model_backward_ex(const float* x, const float* dsr, const float* params, float* grads, void* workspace,
                             size_t workspace_bytes, int B, int H, int W, int compute, void* stream) {
-  if (compute != 0 && compute != 1) return SIFSR_ERR_ARG;
+  if (compute < 0 || compute > 2) return SIFSR_ERR_ARG;
   return sifsr_engine_backward(x, dsr, params, grads, (float*)workspace, workspace_bytes / sizeof(float), B, H, W, S(stream),
                                compute);
 }
@@ -106,10 +106,10 @@ int sifsr_conv3x3_dgrad(const float* dy, int cout, const float* wdgrad, const fl
 }
 
 // bf16-operand forms (config 5): both bf16 packs live in the second half of the `wdgrad` buffer written by
-// sifsr_pack_conv_weights ([fp32 dgrad pack | bf16 fwd pack | bf16 dgrad pack])
-int sifsr_conv3x3_fwd_bf16(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
-                           const float* scale1, const float* shift1, const float* wdgrad, float* y, int cout,
-                           float* stat_partials, int B, int H, int W, void* stream) {
+// sifsr_pack_conv_weights ([fp32 dgrad pack n | fwd hi n/2 | dgrad hi n/2 | fwd mid | dgrad mid | fwd lo | dgrad lo], n = 9*cin*cout floats)
+static int conv3x3_fwd_lowp(int mode, const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
+                            const float* scale1, const float* shift1, const float* wdgrad, float* y, int cout,
+                            float* stat_partials, int B, int H, int W, void* stream) {
   if (!src0 || !wdgrad || C0 % 16 || (src1 && C1 % 16)) return SIFSR_ERR_SHAPE;
   ConvArgs a;
   a.src[0] = mk_src(src0, C0, scale0, shift0);
@@ -117,13 +117,23 @@ int sifsr_conv3x3_fwd_bf16(const float* src0, int C0, const float* scale0, const
   a.dst[0].ptr = y; a.dst[0].C = cout; a.dst[0].coff = 0; a.dst[1] = a.dst[0];
   a.NQ = a.src[0].nq + a.src[1].nq;
   const size_t n = (size_t)9 * (16 * a.NQ) * cout;
-  a.wpack = wdgrad + n; a.bf16 = 1;
+  a.wpack = wdgrad + n; a.bf16 = mode;
   a.addend = nullptr; a.addC = 0; a.stat_partials = stat_partials; a.dst_split = cout / 16;
   a.B = B; a.H = H; a.W = W;
   return launch_conv3x3_mfma(a, cout, 0, S(stream));
 }
-int sifsr_conv3x3_dgrad_bf16(const float* dy, int cout, const float* wdgrad, int cin, float* g0, int C0, float* g1, int C1,
-                             const float* addend, int B, int H, int W, void* stream) {
+int sifsr_conv3x3_fwd_bf16(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
+                           const float* scale1, const float* shift1, const float* wdgrad, float* y, int cout,
+                           float* stat_partials, int B, int H, int W, void* stream) {
+  return conv3x3_fwd_lowp(1, src0, C0, scale0, shift0, src1, C1, scale1, shift1, wdgrad, y, cout, stat_partials, B, H, W, stream);
+}
+int sifsr_conv3x3_fwd_bf16x3(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
+                             const float* scale1, const float* shift1, const float* wdgrad, float* y, int cout,
+                             float* stat_partials, int B, int H, int W, void* stream) {
+  return conv3x3_fwd_lowp(2, src0, C0, scale0, shift0, src1, C1, scale1, shift1, wdgrad, y, cout, stat_partials, B, H, W, stream);
+}
+static int conv3x3_dgrad_lowp(int mode, const float* dy, int cout, const float* wdgrad, int cin, float* g0, int C0, float* g1, int C1,
+                              const float* addend, int B, int H, int W, void* stream) {
   if (cout % 16 || cin % 16 || C0 % 16 || (g1 && (C1 % 16 || C0 + C1 != cin)) || (!g1 && C0 != cin) || (addend && g1))
     return SIFSR_ERR_SHAPE;
   ConvArgs a;
@@ -131,12 +141,21 @@ int sifsr_conv3x3_dgrad_bf16(const float* dy, int cout, const float* wdgrad, int
   a.dst[0].ptr = g0; a.dst[0].C = C0; a.dst[0].coff = 0;
   a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
   const size_t n = (size_t)9 * cin * cout;
-  a.wpack = wdgrad + n + n / 2; a.bf16 = 1;
+  a.wpack = wdgrad + n + n / 2; a.bf16 = mode;
   a.addend = addend; a.addC = cin; a.stat_partials = nullptr; a.dst_split = C0 / 16;
   a.B = B; a.H = H; a.W = W; a.NQ = cout / 16;
   int rc = launch_conv3x3_mfma(a, cin, 1, S(stream));
   if (rc) return rc;
-  return launch_dgrad_border_fix(dy, cout, wdgrad, cin, g0, C0, C0, g1 ? g1 : g0, g1 ? C1 : C0, B, H, W, S(stream), 1);
+  // border fold: bf16 mode rounds its operands like the main kernel; the split mode is exact, so plain fp32 there
+  return launch_dgrad_border_fix(dy, cout, wdgrad, cin, g0, C0, C0, g1 ? g1 : g0, g1 ? C1 : C0, B, H, W, S(stream), mode == 1 ? 1 : 0);
+}
+int sifsr_conv3x3_dgrad_bf16(const float* dy, int cout, const float* wdgrad, int cin, float* g0, int C0, float* g1, int C1,
+                             const float* addend, int B, int H, int W, void* stream) {
+  return conv3x3_dgrad_lowp(1, dy, cout, wdgrad, cin, g0, C0, g1, C1, addend, B, H, W, stream);
+}
+int sifsr_conv3x3_dgrad_bf16x3(const float* dy, int cout, const float* wdgrad, int cin, float* g0, int C0, float* g1, int C1,
+                               const float* addend, int B, int H, int W, void* stream) {
+  return conv3x3_dgrad_lowp(2, dy, cout, wdgrad, cin, g0, C0, g1, C1, addend, B, H, W, stream);
 }
 
 size_t sifsr_conv3x3_wgrad_scratch_floats(int cin, int cout, int nblk) { return (size_t)nblk * wgrad_slab_floats(cin, cout); }

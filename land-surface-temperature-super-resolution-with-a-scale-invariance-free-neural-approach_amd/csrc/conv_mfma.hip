@@ -52,11 +52,37 @@ constexpr unsigned OOB = 0xFFFFFF00u;   // per-lane offset beyond any tensor: bu
 // the fp32 mode -- same lane map (lane (i, kq) holds channels 4kq..4kq+3), fp32 accumulation, fp32 outputs.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 static __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
   bf16x2 p; p[0] = (__bf16)a; p[1] = (__bf16)b;
   return __builtin_bit_cast(unsigned, p);
 }
 static __device__ __forceinline__ uint2 pack_bf16x4(float4 v) { return make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+// exact three-way split x = hi + mid + lo, each a bf16 (8 + 8 + 8 significand bits cover fp32's 24): the remainders
+// x - hi and x - hi - mid are exact in fp32, so the split loses nothing but underflow
+static __device__ __forceinline__ float4 unpack_bf16x4(uint2 u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xFFFF0000u));
+}
+static __device__ __forceinline__ void split3_bf16x4(float4 v, uint2& hi, uint2& mid, uint2& lo) {
+  hi = make_uint2(0u, 0u); mid = hi; lo = hi;
+  {
+    bf16x2 a, b; a[0] = (__bf16)v.x; a[1] = (__bf16)v.y; b[0] = (__bf16)v.z; b[1] = (__bf16)v.w;
+    hi = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+  }
+  const float4 h = unpack_bf16x4(hi);
+  const float4 r = make_float4(v.x - h.x, v.y - h.y, v.z - h.z, v.w - h.w);
+  {
+    bf16x2 a, b; a[0] = (__bf16)r.x; a[1] = (__bf16)r.y; b[0] = (__bf16)r.z; b[1] = (__bf16)r.w;
+    mid = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+  }
+  const float4 m = unpack_bf16x4(mid);
+  const float4 r2 = make_float4(r.x - m.x, r.y - m.y, r.z - m.z, r.w - m.w);
+  {
+    bf16x2 a, b; a[0] = (__bf16)r2.x; a[1] = (__bf16)r2.y; b[0] = (__bf16)r2.z; b[1] = (__bf16)r2.w;
+    lo = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+  }
+}
 static __device__ __forceinline__ float round_bf16(float a) { return (float)(__bf16)a; }
 static __device__ __forceinline__ float4 round_bf16x4(float4 v) { return make_float4(round_bf16(v.x), round_bf16(v.y), round_bf16(v.z), round_bf16(v.w)); }
 static __device__ __forceinline__ uint2 bload2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -71,13 +97,18 @@ static __device__ __forceinline__ uint2 bload2(__amdgpu_buffer_rsrc_t r, unsigne
 // One s_barrier per work item hands a filled buffer to the consumers and a drained one back to the producers
 // (double-buffered LDS), so the producers' VALU / VMEM / LDS-write instructions issue in the shadow of the
 // consumers' 32-cycle MFMAs on the same SIMD instead of in a separate phase of the same wave.
-template <int NB, bool ZERO_PAD, bool BF16>
+// MODE 0: fp32 MFMA.  1: bf16 operands (config 5).  2: "fp32 on the bf16 matrix cores": every operand is split
+// exactly into three bf16 terms while staging (x = hi + mid + lo) and six of the nine cross products are accumulated
+// (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are <= 2^-24 relative, the size of one fp32 rounding):
+// six v_mfma_f32_16x16x16_bf16 (8 cycles each) replace four v_mfma_f32_16x16x4_f32 (32 cycles each) per 16 channels.
+template <int NB, bool ZERO_PAD, int MODE>
 __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(const ConvArgs a, const int ntiles, const int lgx,
                                                            const int lgy) {
+  constexpr bool BF16 = MODE != 0, X3 = MODE == 2;
   constexpr int CBW = NB >= 4 ? NB / 4 : 1;                 // cout blocks per consumer wave
   constexpr int NG = NB == 1 ? 4 : (NB == 2 ? 8 : 16);      // tile rows per consumer wave
 
-  __shared__ float4 lds[2][4 * PLANE];
+  __shared__ float4 lds[2][(X3 ? 6 : 4) * PLANE];   // X3: three planes of 8 B per (pixel, channel quad)
   __shared__ float red[4][CBW][16][2];
 
   const int tid = threadIdx.x;
@@ -183,7 +214,14 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
         float4 v = stg[it];
         if (!praw) v = bn_relu4(v, psc, psh);
         if (it < 5 || pslot < PW * PW - 320) {
-          if (BF16) reinterpret_cast<uint2*>(Lb)[cg * PLANE + pslot + 64 * it] = pack_bf16x4(v);
+          if (X3) {
+            uint2 hi, mid, lo;
+            split3_bf16x4(v, hi, mid, lo);
+            uint2* const L2 = reinterpret_cast<uint2*>(Lb);
+            L2[cg * PLANE + pslot + 64 * it] = hi;
+            L2[4 * PLANE + cg * PLANE + pslot + 64 * it] = mid;
+            L2[8 * PLANE + cg * PLANE + pslot + 64 * it] = lo;
+          } else if (BF16) reinterpret_cast<uint2*>(Lb)[cg * PLANE + pslot + 64 * it] = pack_bf16x4(v);
           else Lb[cg * PLANE + pslot + 64 * it] = v;
         }
       }
@@ -210,10 +248,12 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
   const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.addend ? a.addend : a.dst[0].ptr, npix * (a.addend ? a.addC : a.dst[0].C) * 4u);
   const bool bn_stats = NB == 1 && ZERO_PAD && a.bn_y != nullptr;     // BatchNorm-backward sums of the previous layer
   const __amdgpu_buffer_rsrc_t rby = make_rsrc(bn_stats ? a.bn_y : a.dst[0].ptr, npix * 64u);
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpack, (unsigned)(NB * 16) * (unsigned)(NQ * 16) * (BF16 ? 18u : 36u));
+  const unsigned wplane = (unsigned)(NB * 16) * (unsigned)(NQ * 16) * 36u;     // X3: byte distance hi -> mid -> lo pack (= 4n)
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpack, X3 ? 2u * wplane + wplane / 2u : (unsigned)(NB * 16) * (unsigned)(NQ * 16) * (BF16 ? 18u : 36u));
 
   float4 wf[BF16 ? 1 : CBW][BF16 ? 1 : 9];
   uint2 wh[BF16 ? CBW : 1][BF16 ? 9 : 1];     // bf16 mode: 4 bf16 per lane per (cout block, tap)
+  uint2 wm[X3 ? CBW : 1][X3 ? 9 : 1], wl[X3 ? CBW : 1][X3 ? 9 : 1];   // X3: the mid / lo terms of the weights
   auto load_weights = [&](int q) {
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
@@ -221,7 +261,13 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
       if (BF16) {
         const unsigned soff = (unsigned)((nb * NQ + q) * 9) * 512u;
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) wh[c][tp] = bload2(rw, (unsigned)lane * 8u, soff + tp * 512u);
+        for (int tp = 0; tp < 9; ++tp) {
+          wh[c][tp] = bload2(rw, (unsigned)lane * 8u, soff + tp * 512u);
+          if (X3) {
+            wm[c][tp] = bload2(rw, (unsigned)lane * 8u, soff + tp * 512u + wplane);
+            wl[c][tp] = bload2(rw, (unsigned)lane * 8u, soff + tp * 512u + 2u * wplane);
+          }
+        }
       } else {
         const unsigned soff = (unsigned)((nb * NQ + q) * 9) * 1024u;
 #pragma unroll
@@ -277,31 +323,74 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
     const int qn = last_q ? 0 : q + 1;
     __builtin_amdgcn_s_setprio(3);
     if (BF16) {
+      // v_mfma_f32_16x16x32_bf16 (16 cycles for K = 32; the K = 16 form of gfx90a takes the same 16): one MFMA contracts the
+      // 16 channels of TWO taps.  Lane (i, kq) holds k = 8*kq .. 8*kq+7 = channels 4kq..4kq+3 of the first tap, then of the
+      // second -- exactly the two 8-byte words the per-tap layout already has, for the weights and for the staged operand.
+      // Pairs (0,1) (2,3) (4,5) (6,7) (8,-): the last one runs with zero weights in its upper half.
       const uint2* L16 = reinterpret_cast<const uint2*>(L);
+      auto cat = [](uint2 lo, uint2 hi) { return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y)); };
+      const uint2 z2 = make_uint2(0u, 0u);
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {
-        const int ty = tp / 3, tx = tp - 3 * (tp / 3);
+      for (int p = 0; p < 5; ++p) {
+        const int t0 = 2 * p, t1 = 2 * p + 1 < 9 ? 2 * p + 1 : 8;
+        const bool two = 2 * p + 1 < 9;
+        const int ty0 = t0 / 3, tx0 = t0 - 3 * (t0 / 3), ty1 = t1 / 3, tx1 = t1 - 3 * (t1 / 3);
 #pragma unroll
         for (int gb = 0; gb < NG / 4; ++gb) {
-          s16x4 bh[4];
+          bf16x8 bh[4], bm[X3 ? 4 : 1], bl[X3 ? 4 : 1];
 #pragma unroll
           for (int gi = 0; gi < 4; ++gi) {
             const int r = g0 + gb * 4 + gi;
-            bh[gi] = __builtin_bit_cast(s16x4, L16[kq * PLANE + (r + ty) * PW + tx + px]);
+            const int o0 = kq * PLANE + (r + ty0) * PW + tx0 + px, o1 = kq * PLANE + (r + ty1) * PW + tx1 + px;
+            bh[gi] = cat(L16[o0], L16[o1]);
+            if (X3) {
+              bm[gi] = cat(L16[4 * PLANE + o0], L16[4 * PLANE + o1]);
+              bl[gi] = cat(L16[8 * PLANE + o0], L16[8 * PLANE + o1]);
+            }
           }
 #pragma unroll
           for (int c = 0; c < CBW; ++c) {
-            const s16x4 w = __builtin_bit_cast(s16x4, wh[c][tp]);
+            const bf16x8 w = cat(wh[c][t0], two ? wh[c][t1] : z2);
+            if (X3) {
+              // smallest terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, then hi*hi
+              const bf16x8 wmid = cat(wm[c][t0], two ? wm[c][t1] : z2), wlo = cat(wl[c][t0], two ? wl[c][t1] : z2);
+#pragma unroll
+              for (int gi = 0; gi < 4; ++gi)
+                acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, bh[gi], acc[c][gb * 4 + gi], 0, 0, 0);
+#pragma unroll
+              for (int gi = 0; gi < 4; ++gi)
+                acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bl[gi], acc[c][gb * 4 + gi], 0, 0, 0);
+#pragma unroll
+              for (int gi = 0; gi < 4; ++gi)
+                acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, bm[gi], acc[c][gb * 4 + gi], 0, 0, 0);
+#pragma unroll
+              for (int gi = 0; gi < 4; ++gi)
+                acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, bh[gi], acc[c][gb * 4 + gi], 0, 0, 0);
+#pragma unroll
+              for (int gi = 0; gi < 4; ++gi)
+                acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bm[gi], acc[c][gb * 4 + gi], 0, 0, 0);
+            }
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi)
-              acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w, bh[gi], acc[c][gb * 4 + gi], 0, 0, 0);
+              acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bh[gi], acc[c][gb * 4 + gi], 0, 0, 0);
           }
         }
         {
-          __builtin_amdgcn_sched_barrier(0);   // keep the prefetch behind this tap's MFMAs: hoisted, it doubles the live weights
+          __builtin_amdgcn_sched_barrier(0);   // keep the prefetch behind this pair's MFMAs: hoisted, it doubles the live weights
 #pragma unroll
-          for (int c = 0; c < CBW; ++c)
-            wh[c][tp] = bload2(rw, (unsigned)lane * 8u, (unsigned)(((nb0 + 4 * c) * NQ + qn) * 9 + tp) * 512u);
+          for (int c = 0; c < CBW; ++c) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              if (k == 1 && !two) continue;
+              const int tp = k == 0 ? t0 : t1;
+              const unsigned so = (unsigned)(((nb0 + 4 * c) * NQ + qn) * 9 + tp) * 512u;
+              wh[c][tp] = bload2(rw, (unsigned)lane * 8u, so);
+              if (X3) {
+                wm[c][tp] = bload2(rw, (unsigned)lane * 8u, so + wplane);
+                wl[c][tp] = bload2(rw, (unsigned)lane * 8u, so + 2u * wplane);
+              }
+            }
+          }
         }
       }
     } else {
@@ -452,14 +541,22 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
       const int NQ = cout / 16;
       const int q = r2 % NQ, nb = r2 / NQ;
       const int co = 16 * q + 4 * (lane >> 4) + j, ci = 16 * nb + (lane & 15);
-      wdg[2 * tb.p_off[l] + e] = W[(co * cin + ci) * 9 + (8 - tap)];
+      wdg[4 * tb.p_off[l] + e] = W[(co * cin + ci) * 9 + (8 - tap)];
     }
     {
-      // bf16 fragment packs (same element order): [fwd | dgrad], 2 bytes each, in the second half of the layer's
-      // dgrad buffer (n floats = 2n + 2n bytes)
-      __bf16* h = reinterpret_cast<__bf16*>(wdg + 2 * tb.p_off[l] + n);
-      h[e] = (__bf16)wfwd[tb.p_off[l] + e];
-      h[n + e] = (__bf16)wdg[2 * tb.p_off[l] + e];
+      // bf16 fragment packs (same element order), 2 bytes each, behind the layer's fp32 dgrad pack (4n floats in all):
+      //   [fp32 dgrad n | fwd hi n/2 | dgrad hi n/2 | fwd mid | dgrad mid | fwd lo | dgrad lo]
+      // hi = bf16(w) is the pack of the bf16 mode; hi + mid + lo = w exactly (the split-bf16 "fp32" mode)
+      __bf16* h = reinterpret_cast<__bf16*>(wdg + 4 * tb.p_off[l] + n);
+      const float wv[2] = {wfwd[tb.p_off[l] + e], wdg[4 * tb.p_off[l] + e]};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const __bf16 hi = (__bf16)wv[k];
+        const float r = wv[k] - (float)hi;
+        const __bf16 mid = (__bf16)r;
+        const __bf16 lo = (__bf16)(r - (float)mid);
+        h[k * n + e] = hi; h[2 * n + k * n + e] = mid; h[4 * n + k * n + e] = lo;
+      }
     }
   }
 }
@@ -643,6 +740,7 @@ int conv3x3_grid_blocks(int B, int H, int W, int cout) {
 
 int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s) {
   if (a.H < 1 || a.W < 1 || cout % 16 || a.NQ < 1 || a.src[0].nq + a.src[1].nq != a.NQ) return SIFSR_ERR_SHAPE;
+  if (a.bf16 < 0 || a.bf16 > 2) return SIFSR_ERR_ARG;
   if (!a.src[0].ptr || !a.dst[0].ptr || !a.wpack) return SIFSR_ERR_ARG;
   const int ntiles = a.B * ((a.H + 15) / 16) * ((a.W + 15) / 16);
   const dim3 grid(conv3x3_grid_blocks(a.B, a.H, a.W, cout)), block(512);
@@ -658,15 +756,12 @@ int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s
   if (!pow2(a.src[0].C) || (a.src[1].ptr && !pow2(a.src[1].C))) return SIFSR_ERR_SHAPE;
   const int tx_ = (a.W + 15) / 16, ty_ = (a.H + 15) / 16;
   const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
+#define SIFSR_CONV_LAUNCH(NBV, ZP, MD) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, ZP, MD>), grid, block, 0, s, a, ntiles, lgx, lgy)
 #define SIFSR_CONV_CASE(NBV)                                                                              \
   case NBV:                                                                                               \
-    if (a.bf16) {                                                                                         \
-      if (zero_pad) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, true, true>), grid, block, 0, s, a, ntiles, lgx, lgy);   \
-      else hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, false, true>), grid, block, 0, s, a, ntiles, lgx, lgy);           \
-    } else {                                                                                              \
-      if (zero_pad) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, true, false>), grid, block, 0, s, a, ntiles, lgx, lgy);  \
-      else hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, false, false>), grid, block, 0, s, a, ntiles, lgx, lgy);          \
-    }                                                                                                     \
+    if (a.bf16 == 2) { if (zero_pad) SIFSR_CONV_LAUNCH(NBV, true, 2); else SIFSR_CONV_LAUNCH(NBV, false, 2); }      \
+    else if (a.bf16) { if (zero_pad) SIFSR_CONV_LAUNCH(NBV, true, 1); else SIFSR_CONV_LAUNCH(NBV, false, 1); }      \
+    else { if (zero_pad) SIFSR_CONV_LAUNCH(NBV, true, 0); else SIFSR_CONV_LAUNCH(NBV, false, 0); }                   \
     break;
   switch (nb) {
     SIFSR_CONV_CASE(1)
@@ -676,6 +771,7 @@ int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s
     default: return SIFSR_ERR_SHAPE;
   }
 #undef SIFSR_CONV_CASE
+#undef SIFSR_CONV_LAUNCH
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

@@ -79,7 +79,7 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
 
   w.mean = take(nt.total_channels); w.invstd = take(nt.total_channels);
   w.scale = take(nt.total_channels); w.shift = take(nt.total_channels);
-  w.wfwd = take(nt.total_wpack); w.wdg = take(2 * (size_t)nt.total_wpack);
+  w.wfwd = take(nt.total_wpack); w.wdg = take(4 * (size_t)nt.total_wpack);
   for (int l = 0; l < SIFSR_NUM_BN_LAYERS; ++l) w.y[l] = take(nt.L[l].cout * N[nt.L[l].level]);
   static const int pc[3] = {16, 32, 64};
   for (int k = 0; k < 3; ++k) {
@@ -132,7 +132,7 @@ struct Ctx {
   hipStream_t s;
   WgradReduceJob* jobs = nullptr;   // backward: slab reductions deferred to one batched launch
   int* njobs = nullptr;
-  int bf16 = 0;                     // config 5: bf16 MFMA operands in the 3x3 conv forward / dgrad
+  int bf16 = 0;                     // 1: bf16 MFMA operands (config 5); 2: split-bf16 fp32 (conv forward / dgrad; wgrad stays fp32)
   struct SideLane* side = nullptr;  // backward: the weight gradients' own stream (nullptr = everything on s)
   int lvH(int lv) const { return H >> lv; }
   int lvW(int lv) const { return W >> lv; }
@@ -235,7 +235,7 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
   a.bf16 = c.bf16;
   {
     const size_t n = (size_t)9 * L.cin * L.cout;   // bf16 packs live in the second half of the layer's dgrad buffer
-    a.wpack = c.bf16 ? c.f(c.lay.wdg) + 2 * (size_t)L.wpack_off + n : c.f(c.lay.wfwd) + L.wpack_off;
+    a.wpack = c.bf16 ? c.f(c.lay.wdg) + 4 * (size_t)L.wpack_off + n : c.f(c.lay.wfwd) + L.wpack_off;
   }
   a.addend = nullptr; a.addC = 0;
   a.stat_partials = training ? c.f(c.lay.partials) : nullptr;
@@ -298,7 +298,7 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
   a.B = c.B; a.H = c.lvH(L.level); a.W = c.lvW(L.level);
   a.NQ = L.cin / 16;
   a.ntiles = c.B * ((a.H + 7) / 8) * ((a.W + 15) / 16);
-  a.bf16 = c.bf16;
+  a.bf16 = c.bf16 == 1 ? 1 : 0;   // the split-bf16 mode keeps the fp32 weight-gradient kernel
   const int nbi = wgrad_nbi_chunk(a, L.cin);
   const int nblk = wgrad_blocks(L.cin, L.cout, L.cin / (16 * nbi), a.ntiles);
   hipStream_t ws = c.s;
@@ -336,7 +336,7 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
   a.dst[0].ptr = g0; a.dst[0].C = C0; a.dst[0].coff = 0;
   a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
   a.bf16 = c.bf16;
-  const float* wdg_f32 = c.f(c.lay.wdg) + 2 * (size_t)L.wpack_off;
+  const float* wdg_f32 = c.f(c.lay.wdg) + 4 * (size_t)L.wpack_off;
   {
     const size_t n = (size_t)9 * L.cin * L.cout;
     a.wpack = c.bf16 ? wdg_f32 + n + n / 2 : wdg_f32;   // [fp32 dgrad | bf16 fwd (n/2 floats) | bf16 dgrad]
@@ -356,7 +356,7 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
     SIFSR_TRY(launch_conv3x3_mfma(a, L.cin, 1, c.s));
   }
   SIFSR_TRY(launch_dgrad_border_fix(dy, L.cout, wdg_f32, L.cin, g0, C0, split_ch, g1 ? g1 : g0, g1 ? C1 : C0, c.B, a.H,
-                                    a.W, c.s, c.bf16, fuse ? a.bn_y : nullptr, fuse ? a.bn_scale : nullptr,
+                                    a.W, c.s, c.bf16 == 1 ? 1 : 0, fuse ? a.bn_y : nullptr, fuse ? a.bn_scale : nullptr,
                                     fuse ? a.bn_shift : nullptr, fuse ? c.f(c.lay.bpart) : nullptr));
   return SIFSR_OK;
 }
@@ -371,7 +371,8 @@ int sifsr_engine_forward(const float* x, float* sr, const float* params, float* 
                          hipStream_t s, int bf16) {
   if (!x || !sr || !params || !running || !ws) return SIFSR_ERR_ARG;
   Ctx c{sifsr_net(), WsLayout(), ws, params, B, H, W, s};
-  c.bf16 = bf16 ? 1 : 0;
+  if (bf16 < 0 || bf16 > 2) return SIFSR_ERR_ARG;
+  c.bf16 = bf16;
   SIFSR_TRY(sifsr_layout(B, H, W, training, &c.lay));
   if (ws_floats < c.lay.total) return SIFSR_ERR_WORKSPACE;
   const NetTable& nt = c.nt;
@@ -435,7 +436,8 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
                           size_t ws_floats, int B, int H, int W, hipStream_t s, int bf16) {
   if (!x || !dsr || !params || !grads || !ws) return SIFSR_ERR_ARG;
   Ctx c{sifsr_net(), WsLayout(), ws, params, B, H, W, s};
-  c.bf16 = bf16 ? 1 : 0;
+  if (bf16 < 0 || bf16 > 2) return SIFSR_ERR_ARG;
+  c.bf16 = bf16;
   SIFSR_TRY(sifsr_layout(B, H, W, 1, &c.lay));
   if (ws_floats < c.lay.total) return SIFSR_ERR_WORKSPACE;
   const NetTable& nt = c.nt;

@@ -57,6 +57,13 @@ class _Up(nn.Module):
         self.convbloc = _Bloc(cin, cout, cin // 2, padding_mode)                     # model.py:208
 
 
+# compute modes of the 3x3 convolutions (sifsr_model_*_ex): "fp32" = fp32 MFMA (default, the parity configuration);
+# "bf16" = bf16 operands, fp32 accumulation (BASELINE.json config 5); "bf16x3" = fp32 on the bf16 matrix cores: every
+# operand split exactly into three bf16 terms, six of nine cross products accumulated (forward and input gradient; the
+# weight gradient stays on the fp32 MFMA) -- agrees with "fp32" to fp32 rounding
+_COMPUTE_MODES = {"fp32": 0, "bf16": 1, "bf16x3": 2}
+
+
 class _ModelFn(torch.autograd.Function):
     """One autograd node for the whole network: forward / backward are single C-ABI calls."""
 
@@ -78,7 +85,9 @@ class _ModelFn(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         sr = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
         bn = module._bn_hyper
-        compute = 1 if getattr(module, "compute_dtype", "fp32") == "bf16" else 0
+        compute = _COMPUTE_MODES.get(getattr(module, "compute_dtype", "fp32"))
+        if compute is None:
+            raise _lib.SifsrError(f"compute_dtype must be one of {sorted(_COMPUTE_MODES)}")
         _lib.call("sifsr_model_forward_ex", x, sr, flat_p, flat_r, flat_n, ws, ws_bytes, B, H, W,
                   1 if training else 0, bn[0], bn[1], compute, _lib.stream_ptr(x.device))
         ctx.compute = compute

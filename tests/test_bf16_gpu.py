@@ -102,7 +102,7 @@ def test_bf16_conv_kernels_exact_arithmetic(sifsr, case):
     wa = w.clone().requires_grad_(True)
     (gw_ref,) = torch.autograd.grad(conv(rb(x), wa), wa, rb(dy))
     S = torch.cuda.current_stream().cuda_stream
-    wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(2 * 9 * cin * cout, device="cuda")
+    wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(4 * 9 * cin * cout, device="cuda")
     L.call("sifsr_pack_conv_weights", w.cuda(), cin, cout, wf, wd, S)
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
     y = torch.empty(B, H, W, cout, device="cuda"); gx = torch.empty(B, H, W, cin, device="cuda")

@@ -99,7 +99,7 @@ def test_conv3x3_fwd_dgrad_wgrad(L, case):
     d1 = dev(nhwc(x1)) if C1 else None
     dsc0, dsh0 = (dev(sc0), dev(sh0)) if aff0 else (None, None)
     dsc1, dsh1 = (dev(sc1), dev(sh1)) if sc1 is not None else (None, None)
-    wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(2 * 9 * cin * cout, device="cuda")
+    wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(4 * 9 * cin * cout, device="cuda")
     L.call("sifsr_pack_conv_weights", dw_, cin, cout, wf, wd, S())
 
     # ---- forward + BN statistic partials ----
@@ -368,7 +368,7 @@ def test_conv3x3_full_size_grids(L, shape):
     y_ref = conv_rep(a, w)
     dy = rnd(rs, B, cout, H, W)
     (ga_ref,) = torch.autograd.grad((y_ref * dy).sum(), [a])
-    wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(2 * 9 * cin * cout, device="cuda")
+    wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(4 * 9 * cin * cout, device="cuda")
     dw_ = dev(w)
     L.call("sifsr_pack_conv_weights", dw_, cin, cout, wf, wd, S())
     dx, ddy = dev(nhwc(x)), dev(nhwc(dy))

@@ -9,12 +9,13 @@ cout = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 H = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 B = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 20
+mode = sys.argv[7] if len(sys.argv) > 7 else "fp32"      # fp32 | bf16 | bf16x3 (fwd / dgrad only)
 dev = "cuda"
 torch.manual_seed(0)
 x = torch.randn(B, H, H, cin, device=dev)
 sc = torch.rand(cin, device=dev) + 0.5; sh = torch.randn(cin, device=dev) * 0.3
 w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5
-wf = torch.empty(9 * cin * cout, device=dev); wd = torch.empty(2 * 9 * cin * cout, device=dev)
+wf = torch.empty(9 * cin * cout, device=dev); wd = torch.empty(4 * 9 * cin * cout, device=dev)
 S = torch.cuda.current_stream().cuda_stream
 L.call("sifsr_pack_conv_weights", w, cin, cout, wf, wd, S)
 y = torch.empty(B, H, H, cout, device=dev)
@@ -25,10 +26,14 @@ nblk = int(os.environ.get("NBLK", 2048 if 9 * cin * cout <= 4608 else 1024))
 scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_scratch_floats", cin, cout, nblk), device=dev)
 dw = torch.empty_like(w)
 def run():
-    if op == "fwd":
+    if op == "fwd" and mode == "fp32":
         L.call("sifsr_conv3x3_fwd", x, cin, sc, sh, None, 0, None, None, wf, y, cout, part, B, H, H, S)
-    elif op == "dgrad":
+    elif op == "fwd":
+        L.call("sifsr_conv3x3_fwd_" + mode, x, cin, sc, sh, None, 0, None, None, wd, y, cout, part, B, H, H, S)
+    elif op == "dgrad" and mode == "fp32":
         L.call("sifsr_conv3x3_dgrad", dy, cout, wd, w, cin, g, cin, None, 0, None, B, H, H, S)
+    elif op == "dgrad":
+        L.call("sifsr_conv3x3_dgrad_" + mode, dy, cout, wd, cin, g, cin, None, 0, None, B, H, H, S)
     else:
         L.call("sifsr_conv3x3_wgrad", x, cin, sc, sh, None, 0, None, None, dy, cout, scratch, nblk, dw, B, H, H, S)
 for _ in range(3): run()
@@ -39,4 +44,4 @@ for _ in range(iters): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 fl = 2 * 9 * cin * cout * H * H * B
-print(f"{op} {cin}->{cout} @{H}^2 B={B}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s ({fl/ms/1e9/157.3*100:.1f}% of fp32 MFMA peak)")
+print(f"[{mode}] {op} {cin}->{cout} @{H}^2 B={B}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s ({fl/ms/1e9/157.3*100:.1f}% of fp32 MFMA peak)")

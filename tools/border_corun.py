@@ -9,7 +9,7 @@ torch.manual_seed(0)
 x = torch.randn(B, H, H, cin, device=dev); dy = torch.randn(B, H, H, cout, device=dev)
 sc = torch.rand(cin, device=dev) + 0.5; sh = torch.randn(cin, device=dev) * 0.3
 w = torch.randn(cout, cin, 3, 3, device=dev) * 0.1
-wf = torch.empty(9 * cin * cout, device=dev); wd = torch.empty(2 * 9 * cin * cout, device=dev)
+wf = torch.empty(9 * cin * cout, device=dev); wd = torch.empty(4 * 9 * cin * cout, device=dev)
 g = torch.empty(B, H, H, cin, device=dev)
 nblk = 1024
 scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_scratch_floats", cin, cout, nblk), device=dev)

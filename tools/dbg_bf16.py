@@ -9,7 +9,7 @@ rb = lambda t: t.to(torch.bfloat16).float()
 conv = lambda a, b: F.conv2d(F.pad(a, (1, 1, 1, 1), mode="replicate"), b)
 y32, y16 = conv(x, w), conv(rb(x), rb(w))
 S = torch.cuda.current_stream().cuda_stream
-wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(2 * 9 * cin * cout, device="cuda")
+wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(4 * 9 * cin * cout, device="cuda")
 L.call("sifsr_pack_conv_weights", w.cuda(), cin, cout, wf, wd, S)
 xd = x.permute(0, 2, 3, 1).contiguous().cuda()
 y = torch.empty(B, H, W, cout, device="cuda")

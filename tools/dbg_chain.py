@@ -45,7 +45,7 @@ name = "ub2.convbloc.bloc.0"
 w = s[name + ".weight"]; xin, y = tape[id(w)]
 dy64, gin64 = y.grad, xin.grad            # (B,32,128,128), (B,64,128,128)
 cout, cin, H = 32, 64, 128
-wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(2 * 9 * cin * cout, device="cuda"); dw_ = dev(w.detach().float())
+wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(4 * 9 * cin * cout, device="cuda"); dw_ = dev(w.detach().float())
 L.call("sifsr_pack_conv_weights", dw_, cin, cout, wf, wd, S())
 g0 = torch.empty(B, H, H, 32, device="cuda"); g1 = torch.empty(B, H, H, 32, device="cuda")
 L.call("sifsr_conv3x3_dgrad", dev(nhwc(dy64.float())), cout, wd, dw_, cin, g0, 32, g1, 32, None, B, H, H, S()); torch.cuda.synchronize()

@@ -24,7 +24,7 @@ for (C0, C1, cout, H, B) in ((32, 32, 32, 128, 2), (64, 64, 64, 64, 2), (16, 16,
     y = conv_rep(a, w)
     dy = border_boost(rnd(rs, B, cout, H, H))
     (ga,) = torch.autograd.grad((y * dy).sum(), [a])
-    wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(2 * 9 * cin * cout, device="cuda"); dw_ = dev(w)
+    wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(4 * 9 * cin * cout, device="cuda"); dw_ = dev(w)
     L.call("sifsr_pack_conv_weights", dw_, cin, cout, wf, wd, S())
     g0 = torch.empty(B, H, H, C0, device="cuda"); g1 = torch.empty(B, H, H, C1, device="cuda") if C1 else None
     L.call("sifsr_conv3x3_dgrad", dev(nhwc(dy)), cout, wd, dw_, cin, g0, C0, g1, C1, None, B, H, H, S()); torch.cuda.synchronize()
