@@ -53,7 +53,8 @@ SIFSR_API int sifsr_model_backward(const float* x, const float* dsr, const float
 /* The same two calls with a compute mode: 0 = fp32 (identical to the calls above), 1 = BASELINE.json config 5,
  * "bf16 mixed precision, MFMA-bf16 conv tiles": the operands of the sixteen 3x3 MFMA convs (activations after
  * BatchNorm+ReLU, weights, and dy in the input-gradient pass) are rounded to bf16 while staging and contracted with
- * v_mfma_f32_16x16x16_bf16 (the weight-gradient pass rounds x and dy the same way); accumulation, stored
+ * v_mfma_f32_16x16x32_bf16, two taps per MFMA (the weight-gradient pass rounds x and dy the same way and uses the K = 16
+ * form over 16 pixels); accumulation, stored
  * activations, BatchNorm, the two thin convs and the parameters stay fp32.  Forward and backward of one step must use the same mode. */
 SIFSR_API int sifsr_model_forward_ex(const float* x, float* sr, const float* params, float* running, long long* nbt,
                                      void* workspace, size_t workspace_bytes, int B, int H, int W, int training,
@@ -79,7 +80,7 @@ SIFSR_API int sifsr_conv3x3_dgrad(const float* dy, int cout, const float* wdgrad
                                   float* g0, int C0, float* g1, int C1, const float* addend, int B, int H, int W,
                                   void* stream);
 /* bf16-operand forms of the two calls above (BASELINE.json config 5): operands rounded to bf16 while staging,
- * v_mfma_f32_16x16x16_bf16, fp32 accumulation and output.  Both take the `wdgrad` buffer of
+ * v_mfma_f32_16x16x32_bf16 (two taps per MFMA), fp32 accumulation and output.  Both take the `wdgrad` buffer of
  * sifsr_pack_conv_weights, whose second half holds the bf16 fragment packs [forward | dgrad]. */
 SIFSR_API int sifsr_conv3x3_fwd_bf16(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1,
                                      int C1, const float* scale1, const float* shift1, const float* wdgrad, float* y,
@@ -88,8 +89,8 @@ SIFSR_API int sifsr_conv3x3_dgrad_bf16(const float* dy, int cout, const float* w
                                        int C1, const float* addend, int B, int H, int W, void* stream);
 /* split-bf16 forms ("fp32 on the bf16 matrix cores", compute mode 2 of sifsr_model_*_ex): activations and weights are
  * split exactly into three bf16 terms while staging (x = hi + mid + lo) and six of the nine cross products are
- * accumulated in fp32 (the dropped ones are <= 2^-24 relative): six v_mfma_f32_16x16x16_bf16 per 16 channels instead
- * of four v_mfma_f32_16x16x4_f32 at a quarter of the cycles each.  Results agree with the fp32 forms to fp32 rounding. */
+ * accumulated in fp32 (the dropped ones are <= 2^-24 relative): six v_mfma_f32_16x16x32_bf16 per 16 channels of two taps instead
+ * of eight v_mfma_f32_16x16x4_f32 at half the cycles each.  Results agree with the fp32 forms to fp32 rounding. */
 SIFSR_API int sifsr_conv3x3_fwd_bf16x3(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1,
                                        int C1, const float* scale1, const float* shift1, const float* wdgrad, float* y,
                                        int cout, float* stat_partials, int B, int H, int W, void* stream);

@@ -48,7 +48,7 @@ constexpr unsigned OOB = 0xFFFFFF00u;   // per-lane offset beyond any tensor: bu
 
 // ---- bf16 operand mode (BASELINE.json config 5: "bf16 mixed precision, MFMA-bf16 conv tiles") ----
 // Activations and weights stay fp32 in HBM; the producers round them to bf16 (RNE, v_cvt_pk_bf16_f32) while
-// staging, and ONE v_mfma_f32_16x16x16_bf16 contracts the 16 channels that take four v_mfma_f32_16x16x4_f32 in
+// staging, and ONE v_mfma_f32_16x16x32_bf16 (two taps at a time, see the consumer loop) contracts the 16 channels that take four v_mfma_f32_16x16x4_f32 in
 // the fp32 mode -- same lane map (lane (i, kq) holds channels 4kq..4kq+3), fp32 accumulation, fp32 outputs.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -100,7 +100,7 @@ static __device__ __forceinline__ uint2 bload2(__amdgpu_buffer_rsrc_t r, unsigne
 // MODE 0: fp32 MFMA.  1: bf16 operands (config 5).  2: "fp32 on the bf16 matrix cores": every operand is split
 // exactly into three bf16 terms while staging (x = hi + mid + lo) and six of the nine cross products are accumulated
 // (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are <= 2^-24 relative, the size of one fp32 rounding):
-// six v_mfma_f32_16x16x16_bf16 (8 cycles each) replace four v_mfma_f32_16x16x4_f32 (32 cycles each) per 16 channels.
+// six v_mfma_f32_16x16x32_bf16 (16 cycles each, two taps per MFMA) replace eight v_mfma_f32_16x16x4_f32 (32 cycles each) per 16 channels.
 template <int NB, bool ZERO_PAD, int MODE>
 __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(const ConvArgs a, const int ntiles, const int lgx,
                                                            const int lgy) {
