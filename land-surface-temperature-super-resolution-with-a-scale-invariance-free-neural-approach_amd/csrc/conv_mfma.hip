@@ -102,11 +102,15 @@ static __device__ __forceinline__ uint2 bload2(__amdgpu_buffer_rsrc_t r, unsigne
 // (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are <= 2^-24 relative, the size of one fp32 rounding):
 // six v_mfma_f32_16x16x32_bf16 (16 cycles each, two taps per MFMA) replace eight v_mfma_f32_16x16x4_f32 (32 cycles each) per 16 channels.
 template <int NB, bool ZERO_PAD, int MODE>
-__global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(const ConvArgs a, const int ntiles, const int lgx,
+__global__ __launch_bounds__(512, (NB <= 2 && MODE != 2 ? 4 : 2)) void conv3x3_mfma_kernel(const ConvArgs a, const int ntiles, const int lgx,
                                                            const int lgy) {
   constexpr bool BF16 = MODE != 0, X3 = MODE == 2;
-  constexpr int CBW = NB >= 4 ? NB / 4 : 1;                 // cout blocks per consumer wave
-  constexpr int NG = NB == 1 ? 4 : (NB == 2 ? 8 : 16);      // tile rows per consumer wave
+  // X3 with 2 or 4 cout blocks: TWO adjacent blocks per wave and half the rows, so every operand word read from LDS
+  // feeds twice the MFMAs (at 16 cycles per bf16 MFMA and three operand planes the one-block tiling is LDS-bound)
+  constexpr bool PAIR = X3 && (NB == 2 || NB == 4);
+  constexpr int CBW = PAIR ? 2 : (NB >= 4 ? NB / 4 : 1);   // cout blocks per consumer wave
+  constexpr int CST = PAIR ? 1 : 4;                          // ... block nb0 + CST * c
+  constexpr int NG = PAIR ? (NB == 2 ? 4 : 8) : (NB == 1 ? 4 : (NB == 2 ? 8 : 16));   // tile rows per consumer wave
 
   __shared__ float4 lds[2][(X3 ? 6 : 4) * PLANE];   // X3: three planes of 8 B per (pixel, channel quad)
   __shared__ float red[4][CBW][16][2];
@@ -240,8 +244,8 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
   }
 
   // ============================================= CONSUMER =============================================
-  const int nb0 = NB == 1 ? 0 : (NB == 2 ? (wave & 1) : wave);
-  const int g0 = NB == 1 ? wave * 4 : (NB == 2 ? (wave >> 1) * 8 : 0);
+  const int nb0 = PAIR ? (NB == 2 ? 0 : 2 * (wave & 1)) : (NB == 1 ? 0 : (NB == 2 ? (wave & 1) : wave));
+  const int g0 = PAIR ? (NB == 2 ? wave * 4 : (wave >> 1) * 8) : (NB == 1 ? wave * 4 : (NB == 2 ? (wave >> 1) * 8 : 0));
   const int kq = lane >> 4, px = lane & 15;
   const __amdgpu_buffer_rsrc_t rd0 = make_rsrc(a.dst[0].ptr, npix * a.dst[0].C * 4u);
   const __amdgpu_buffer_rsrc_t rd1 = make_rsrc(a.dst[1].ptr, npix * a.dst[1].C * 4u);
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
   auto load_weights = [&](int q) {
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
-      const int nb = nb0 + 4 * c;
+      const int nb = nb0 + CST * c;
       if (BF16) {
         const unsigned soff = (unsigned)((nb * NQ + q) * 9) * 512u;
 #pragma unroll
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
             for (int k = 0; k < 2; ++k) {
               if (k == 1 && !two) continue;
               const int tp = k == 0 ? t0 : t1;
-              const unsigned so = (unsigned)(((nb0 + 4 * c) * NQ + qn) * 9 + tp) * 512u;
+              const unsigned so = (unsigned)(((nb0 + CST * c) * NQ + qn) * 9 + tp) * 512u;
               wh[c][tp] = bload2(rw, (unsigned)lane * 8u, so);
               if (X3) {
                 wm[c][tp] = bload2(rw, (unsigned)lane * 8u, so + wplane);
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
           __builtin_amdgcn_sched_barrier(0);   // keep the prefetch behind this tap's MFMAs: hoisted, it doubles the live weights
 #pragma unroll
           for (int c = 0; c < CBW; ++c)
-            wf[c][tp] = bload4(rw, (unsigned)lane * 16u, (unsigned)(((nb0 + 4 * c) * NQ + qn) * 9 + tp) * 1024u);
+            wf[c][tp] = bload4(rw, (unsigned)lane * 16u, (unsigned)(((nb0 + CST * c) * NQ + qn) * 9 + tp) * 1024u);
         }
       }
     }
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
     const bool do_stats = a.stat_partials != nullptr && !bn_stats;
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
-      const int nb = nb0 + 4 * c;
+      const int nb = nb0 + CST * c;
       const bool d0 = nb < a.dst_split;
       const int dC = d0 ? a.dst[0].C : a.dst[1].C;
       const __amdgpu_buffer_rsrc_t rd = d0 ? rd0 : rd1;
@@ -498,7 +502,10 @@ __global__ __launch_bounds__(512, (NB <= 2 ? 4 : 2)) void conv3x3_mfma_kernel(co
     if (tid < NB * 16) {
       const int nb = tid >> 4, cc = tid & 15;
       float u = 0.f, v = 0.f;
-      if (NB == 1) {
+      if (PAIR) {
+        if (NB == 2) { for (int w = 0; w < 4; ++w) { u += red[w][nb][cc][0]; v += red[w][nb][cc][1]; } }
+        else { for (int w = nb >> 1; w < 4; w += 2) { u += red[w][nb & 1][cc][0]; v += red[w][nb & 1][cc][1]; } }
+      } else if (NB == 1) {
         for (int w = 0; w < 4; ++w) { u += red[w][0][cc][0]; v += red[w][0][cc][1]; }
       } else if (NB == 2) {
         for (int w = nb; w < 4; w += 2) { u += red[w][0][cc][0]; v += red[w][0][cc][1]; }

@@ -232,10 +232,10 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
   a.src[0] = s0; a.src[1] = s1;
   a.dst[0].ptr = c.f(c.lay.y[l]); a.dst[0].C = L.cout; a.dst[0].coff = 0;
   a.dst[1] = a.dst[0];
-  a.bf16 = c.bf16;
+  a.bf16 = (c.bf16 == 2 && L.cout == 128) ? 0 : c.bf16;   // split mode: the 8-block variant has no registers for it -> fp32 MFMA (same results)
   {
-    const size_t n = (size_t)9 * L.cin * L.cout;   // bf16 packs live in the second half of the layer's dgrad buffer
-    a.wpack = c.bf16 ? c.f(c.lay.wdg) + 4 * (size_t)L.wpack_off + n : c.f(c.lay.wfwd) + L.wpack_off;
+    const size_t n = (size_t)9 * L.cin * L.cout;   // bf16 packs live behind the layer's fp32 dgrad pack
+    a.wpack = a.bf16 ? c.f(c.lay.wdg) + 4 * (size_t)L.wpack_off + n : c.f(c.lay.wfwd) + L.wpack_off;
   }
   a.addend = nullptr; a.addC = 0;
   a.stat_partials = training ? c.f(c.lay.partials) : nullptr;
@@ -335,11 +335,11 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
   a.src[0] = src_raw(dy, L.cout); a.src[1] = src_none();
   a.dst[0].ptr = g0; a.dst[0].C = C0; a.dst[0].coff = 0;
   a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
-  a.bf16 = c.bf16;
+  a.bf16 = (c.bf16 == 2 && L.cin == 128) ? 0 : c.bf16;     // see conv_unit_fwd
   const float* wdg_f32 = c.f(c.lay.wdg) + 4 * (size_t)L.wpack_off;
   {
     const size_t n = (size_t)9 * L.cin * L.cout;
-    a.wpack = c.bf16 ? wdg_f32 + n + n / 2 : wdg_f32;   // [fp32 dgrad | bf16 fwd (n/2 floats) | bf16 dgrad]
+    a.wpack = a.bf16 ? wdg_f32 + n + n / 2 : wdg_f32;   // [fp32 dgrad | fwd hi (n/2 floats) | dgrad hi | mid, lo packs]
   }
   a.addend = addend; a.addC = L.cin;
   a.stat_partials = nullptr;
