@@ -1,6 +1,6 @@
 """Layer-by-layer forward parity of the bf16-operand mode (training forward): raw conv outputs y_l from the HIP
 workspace vs the oracle's bf16-operand emulation and vs the fp32 oracle."""
-import sys, os, copy, ctypes; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os, copy, ctypes; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import sifsr
 from sifsr import _lib as L

@@ -1,5 +1,5 @@
 """Isolate per-op error on REALISTIC backward data (fp64 oracle tape -> cast to fp32 -> one HIP op -> compare with fp64)."""
-import sys, os, ctypes; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os, ctypes; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn.functional as F, numpy as np
 import sifsr
 from sifsr import _lib as L

@@ -1,5 +1,5 @@
 """Layer-by-layer parity of the backward pass: dL/dy_l of every conv (HIP workspace) vs the oracle in fp32 and fp64."""
-import sys, os, copy, ctypes; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os, copy, ctypes; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn.functional as F
 import sifsr
 from sifsr import _lib as L

@@ -1,4 +1,4 @@
-import sys, copy; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, copy; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, sifsr
 from oracle import sif_oracle as O
 from tests.conftest import rel_err

@@ -4,7 +4,7 @@ the sixteen 3x3 MFMA convs, fp32 everywhere else.
 Kernel parity is exact-arithmetic: a single conv (forward and input gradient) against the same operands rounded to
 bf16 on the CPU and contracted in fp32 -- 1e-5.  End to end the bar is the arithmetic's own noise: two correct
 bf16-operand pipelines whose fp32 inputs differ by 1e-7 round a few values per thousand to the neighbouring bf16
-(0.4 % apart), 7e-4 after the first MFMA layer and ~1e-2 at the output (tools/dbg_bf16_layers.py) -- the same
+(0.4 % apart), 7e-4 after the first MFMA layer and ~1e-2 at the output (tests/debug_tools/dbg_bf16_layers.py) -- the same
 mechanism as the ReLU mask flips of DESIGN.md §6.  So the network-level checks ask that the HIP result is as close
 to the oracle's bf16-operand emulation as that emulation is to fp32, and closer to fp32 than torch.autocast is."""
 import copy
