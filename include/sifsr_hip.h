@@ -14,8 +14,9 @@
  *                  (conv OIHW weights / BN weight / BN bias per layer, then outlay.weight, outlay.bias)
  *          running: flat fp32 [per BN layer: running_mean(C), running_var(C)], nbt: int64[17]
  *          activations between kernels: NHWC fp32 (internal).
- * H and W must be multiples of 128 for the model entry points (4 resolution levels x 16-pixel tiles)
- * and multiples of 32 for the loss operators.
+ * Sizes: the model entry points take H, W = any multiples of 8 that are >= 24 (three 2x poolings, the reference's own
+ * constraint, model.py:597-603; tiles are masked where a level is not a multiple of the 16x16 conv tile); the loss
+ * operators take any H, W >= 10, multiples of 4 where a /4 decimation is involved.  Other sizes: SIFSR_ERR_SHAPE.
  */
 #ifndef SIFSR_HIP_H
 #define SIFSR_HIP_H

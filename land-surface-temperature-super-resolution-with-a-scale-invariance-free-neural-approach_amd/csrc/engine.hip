@@ -134,6 +134,7 @@ struct Ctx {
   int* njobs = nullptr;
   int bf16 = 0;                     // 1: bf16 MFMA operands (config 5); 2: split-bf16 fp32 (conv forward / dgrad; wgrad stays fp32)
   struct SideLane* side = nullptr;  // backward: the weight gradients' own stream (nullptr = everything on s)
+  bool* forked = nullptr;           // set once anything was enqueued on the side stream (SideLaneGuard)
   int lvH(int lv) const { return H >> lv; }
   int lvW(int lv) const { return W >> lv; }
   float* f(size_t off) const { return ws + off; }
@@ -167,6 +168,7 @@ struct SideLane {
   hipEvent_t ev[SIFSR_NUM_BN_LAYERS] = {};
   hipEvent_t join = nullptr;
   bool ok = false;
+  std::mutex in_use;   // held for a whole backward enqueue: two host threads of one device never interleave on ev[]
 };
 
 int g_side_override = -1;   // sifsr_engine_set_wgrad_stream: -1 = environment default
@@ -175,7 +177,8 @@ SideLane* side_lane(hipStream_t main_stream) {
   static const int env_default = getenv("SIFSR_WGRAD_STREAM") ? atoi(getenv("SIFSR_WGRAD_STREAM")) : 1;   // 0: single stream
   if (!(g_side_override >= 0 ? g_side_override : env_default)) return nullptr;
   static std::mutex mu;
-  static SideLane lanes[16];
+  static SideLane lanes[16];   // per device; events are re-recorded per call, so calls on different caller streams are
+                               // safe as long as their enqueues do not interleave (SideLane::in_use, SideLaneGuard)
   static bool tried[16] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
@@ -204,25 +207,49 @@ SideLane* side_lane(hipStream_t main_stream) {
   return L.ok ? &L : nullptr;
 }
 
+// Holds the lane for one backward call and guarantees the join: once any weight gradient has been forked onto the
+// second stream, EVERY way out of sifsr_engine_backward -- including an early error return -- records the join event
+// behind the side stream's work and makes the caller's stream wait for it, so the caller may free or reuse the
+// workspace / gradient buffers in stream order as with a single-stream call.
+struct SideLaneGuard {
+  SideLane* lane; hipStream_t main; bool forked = false, joined = false;
+  SideLaneGuard(SideLane* l, hipStream_t m) : lane(l), main(m) { if (lane) lane->in_use.lock(); }
+  int join() {
+    if (!lane || joined) return SIFSR_OK;
+    joined = true;
+    if (!forked) return SIFSR_OK;
+    if (hipEventRecord(lane->join, lane->s) != hipSuccess || hipStreamWaitEvent(main, lane->join, 0) != hipSuccess) return SIFSR_ERR_ARG;
+    return SIFSR_OK;
+  }
+  ~SideLaneGuard() { if (lane) { (void)join(); lane->in_use.unlock(); } }
+};
+
 // ---- optional per-kernel timing (bench.py roofline): HIP events on the launch stream around ONE
 // selected (layer, phase) launch inside the normal schedule.  phase 1 fwd conv, 2 dgrad, 3 wgrad.
+// The event pairs are created by sifsr_engine_profile_select (i.e. before the caller's timed region), never inside a
+// launch; a launch that finds the pool exhausted is simply not timed.  One mutex serialises selection, use and read.
 struct ProfState {
   int layer = -1, phase = 0;
-  std::vector<hipEvent_t> start, stop;
+  std::vector<hipEvent_t> start, stop;   // the pool
+  size_t used = 0;
+  std::mutex mu;
 };
 ProfState g_prof;
 
 struct ProfScope {
-  hipStream_t s; bool on;
-  ProfScope(int layer, int phase, hipStream_t st) : s(st), on(layer == g_prof.layer && phase == g_prof.phase) {
-    if (on) {
-      hipEvent_t e0, e1;
-      if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
-      g_prof.start.push_back(e0); g_prof.stop.push_back(e1);
-      (void)hipEventRecord(e0, s);
-    }
+  hipStream_t s; long idx = -1;
+  ProfScope(int layer, int phase, hipStream_t st) : s(st) {
+    if (g_prof.layer < 0) return;   // unlocked fast path: profiling is off (the common case)
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (layer != g_prof.layer || phase != g_prof.phase || g_prof.used >= g_prof.start.size()) return;
+    idx = (long)g_prof.used++;
+    (void)hipEventRecord(g_prof.start[idx], s);
   }
-  ~ProfScope() { if (on) (void)hipEventRecord(g_prof.stop.back(), s); }
+  ~ProfScope() {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if ((size_t)idx < g_prof.stop.size()) (void)hipEventRecord(g_prof.stop[idx], s);
+  }
 };
 
 // forward of one MFMA Conv(-BN) unit
@@ -306,6 +333,7 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
     if (hipEventRecord(c.side->ev[l], c.s) != hipSuccess || hipStreamWaitEvent(c.side->s, c.side->ev[l], 0) != hipSuccess)
       return SIFSR_ERR_ARG;
     ws = c.side->s;
+    if (c.forked) *c.forked = true;
   }
   {
     ProfScope ps(l, 3, ws);
@@ -374,7 +402,10 @@ int sifsr_engine_forward(const float* x, float* sr, const float* params, float* 
   if (bf16 < 0 || bf16 > 2) return SIFSR_ERR_ARG;
   c.bf16 = bf16;
   SIFSR_TRY(sifsr_layout(B, H, W, training, &c.lay));
-  if (ws_floats < c.lay.total) return SIFSR_ERR_WORKSPACE;
+  // a forward touches [0, fwd_end) only; the backward regions behind it are checked by sifsr_engine_backward.  So a
+  // training-mode forward that will never be followed by a backward (torch.no_grad(): BatchNorm recalibration,
+  // frozen-model evaluation in train mode) runs in a forward-sized workspace, as nn.Module allows.
+  if (ws_floats < c.lay.fwd_end) return SIFSR_ERR_WORKSPACE;
   const NetTable& nt = c.nt;
   const WsLayout& w = c.lay;
 
@@ -448,6 +479,8 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   // tiny problems are launch-latency-bound: the 17 event hand-offs cost more than the overlap returns (batch 1 at 256x256:
   // 1.67 ms with the second stream, 1.56 without; batch 4: 1.72 against 1.81)
   c.side = (size_t)B * H * W >= 2u * 65536u || g_side_override == 1 ? side_lane(s) : nullptr;
+  SideLaneGuard lane_guard(c.side, s);
+  c.forked = &lane_guard.forked;
 
   // outlay backward fused with the BatchNorm+ReLU backward of ub3.convbloc.bloc.3 (fused_edges.hip): the outlay
   // input gradient is recomputed from dsr in both passes instead of being stored; dy(L_U3B) -> g[L_U3B]
@@ -543,8 +576,7 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
                                          grads + L.w_off, B, H, W, s));
   }
   if (c.side != nullptr) {   // hand the second stream's work back to the caller's stream
-    if (hipEventRecord(c.side->join, c.side->s) != hipSuccess || hipStreamWaitEvent(s, c.side->join, 0) != hipSuccess)
-      return SIFSR_ERR_ARG;
+    SIFSR_TRY(lane_guard.join());
   } else {
     SIFSR_TRY(launch_wgrad_reduce_batched(ws, jobs, njobs, grads, s));
   }
@@ -560,14 +592,25 @@ int sifsr_engine_set_wgrad_stream(int on) {
 }
 
 int sifsr_engine_profile_select(int layer, int phase) {
-  for (size_t i = 0; i < g_prof.start.size(); ++i) { (void)hipEventDestroy(g_prof.start[i]); (void)hipEventDestroy(g_prof.stop[i]); }
-  g_prof.start.clear(); g_prof.stop.clear();
-  g_prof.layer = layer; g_prof.phase = phase;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  const size_t pool = 4096;   // launches of the selected kernel that can be timed before the next select
+  g_prof.layer = -1;
+  if (layer >= 0) {
+    while (g_prof.start.size() < pool) {
+      hipEvent_t e0, e1;
+      if (hipEventCreate(&e0) != hipSuccess) break;
+      if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); break; }
+      g_prof.start.push_back(e0); g_prof.stop.push_back(e1);
+    }
+  }
+  g_prof.used = 0;
+  g_prof.phase = phase; g_prof.layer = layer;
   return SIFSR_OK;
 }
 int sifsr_engine_profile_read(float* total_ms, int* count) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
   float tot = 0.f; int n = 0;
-  for (size_t i = 0; i < g_prof.start.size(); ++i) {
+  for (size_t i = 0; i < g_prof.used; ++i) {
     float ms = 0.f;
     if (hipEventSynchronize(g_prof.stop[i]) == hipSuccess && hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]) == hipSuccess) { tot += ms; ++n; }
   }

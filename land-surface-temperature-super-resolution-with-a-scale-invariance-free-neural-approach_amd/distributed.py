@@ -65,21 +65,94 @@ def allreduce_flat_(flat: torch.Tensor, average: bool = False):
     return flat
 
 
+def grads_alias_flat(model, flat: torch.Tensor) -> bool:
+    """True when every ``p.grad`` IS the corresponding slice of ``flat`` (autograd adopted the views the backward
+    returned: ``p.grad`` was None before it).  False after ``zero_grad(set_to_none=False)`` or gradient accumulation:
+    ``p.grad`` then owns other memory, into which autograd *added* the new gradient."""
+    off, esz = 0, flat.element_size()
+    for p in model.parameters():
+        if p.grad is None or p.grad.data_ptr() != flat.data_ptr() + off * esz or p.grad.device != flat.device:
+            return False
+        off += p.numel()
+    return off == flat.numel()
+
+
 def allreduce_gradients(model, optimizer=None):
-    """Sum-all-reduce the model's flat gradient buffer (ONE collective).  With a ``FlatAdam``
-    optimizer the 1/world_size is applied inside the Adam kernel (``grad_scale``); otherwise the
-    gradients are divided here."""
+    """Sum-all-reduce the gradients the optimizer will step on, as ONE collective over a flat 282,705-float buffer.
+    With a ``FlatAdam`` optimizer the 1/world_size is applied inside the Adam kernel (``grad_scale``); otherwise the
+    gradients are divided here.
+
+    The fast path reduces the buffer the last backward wrote (``model.flat_grad()``) in place -- valid only if every
+    ``p.grad`` aliases it, which is checked.  Otherwise (accumulated gradients, ``set_to_none=False``) the ``p.grad``
+    tensors themselves are gathered into a flat buffer, reduced, and scattered back, so that no optimizer can step
+    on un-reduced gradients."""
     w = world_size()
     if w == 1:
         return
     flat = model.flat_grad() if hasattr(model, "flat_grad") else None
-    if flat is None:
-        raise RuntimeError("no flat gradient: run backward first")
-    _sum_all_reduce_(flat)
+    params = list(model.parameters())
+    if any(p.grad is None for p in params):
+        raise RuntimeError("allreduce_gradients: a parameter has no gradient -- run backward first")
+    if flat is not None and grads_alias_flat(model, flat):
+        _sum_all_reduce_(flat)
+        if optimizer is not None and hasattr(optimizer, "grad_scale"):
+            optimizer.grad_scale = 1.0 / w
+        else:
+            flat.div_(w)
+        return
+    gathered = torch.cat([p.grad.reshape(-1) for p in params])
+    _sum_all_reduce_(gathered)
     if optimizer is not None and hasattr(optimizer, "grad_scale"):
         optimizer.grad_scale = 1.0 / w
     else:
-        flat.div_(w)
+        gathered.div_(w)
+    off = 0
+    for p in params:
+        p.grad.copy_(gathered[off:off + p.numel()].view_as(p.grad))
+        off += p.numel()
+
+
+def _broadcast_(t: torch.Tensor, src: int):
+    if t.is_cuda and dist.get_backend() == "gloo":
+        host = t.detach().cpu()
+        dist.broadcast(host, src=src)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=src)
+
+
+@torch.no_grad()
+def broadcast_parameters(model, optimizer=None, src: int = 0):
+    """Make rank ``src`` authoritative for everything a replica steps on: the flat parameter buffer, the BatchNorm
+    buffers and -- for ``FlatAdam`` -- the moment buffers and the step count (what DistributedDataParallel does for the
+    module at construction, plus the optimizer state).  Call once after building model + optimizer (and after loading a
+    checkpoint on any rank): replicas that were seeded differently, or of which only one loaded a checkpoint, would
+    otherwise diverge silently, since only gradients are exchanged per step.  A no-op for world_size 1."""
+    if world_size() == 1:
+        return
+    if hasattr(model, "flat_parameters") and next(model.parameters()).is_cuda:
+        _broadcast_(model.flat_parameters(), src)          # one 1.13 MB broadcast; the nn.Parameters are views of it
+    else:
+        for p in model.parameters():
+            _broadcast_(p.data, src)
+    for b in model.buffers():
+        _broadcast_(b, src)
+    if optimizer is not None and hasattr(optimizer, "_m"):
+        dev = next(model.parameters()).device
+        n = sum(p.numel() for p in model.parameters())
+        if optimizer._m is None or optimizer._m.device != dev:
+            optimizer._m = torch.zeros(n, dtype=torch.float32, device=dev)
+            optimizer._v = torch.zeros(n, dtype=torch.float32, device=dev)
+        _broadcast_(optimizer._m, src)
+        _broadcast_(optimizer._v, src)
+        if getattr(optimizer, "capturable", False) and optimizer._step_dev is not None:
+            optimizer._step = int(optimizer._step_dev.item())
+        step = torch.tensor([optimizer._step], dtype=torch.int64)
+        if dist.get_backend() != "gloo":
+            step = step.to(dev)
+        dist.broadcast(step, src=src)
+        optimizer._step = int(step.item())
+        optimizer._step_dev = None
 
 
 def broadcast_buffers(model, src: int = 0):
@@ -88,9 +161,4 @@ def broadcast_buffers(model, src: int = 0):
     if world_size() == 1:
         return
     for b in model.buffers():
-        if b.is_cuda and dist.get_backend() == "gloo":
-            host = b.detach().cpu()
-            dist.broadcast(host, src=src)
-            b.copy_(host)
-        else:
-            dist.broadcast(b, src=src)
+        _broadcast_(b, src)

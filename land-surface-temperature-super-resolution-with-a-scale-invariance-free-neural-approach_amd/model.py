@@ -10,9 +10,14 @@ memory, the stream and the autograd edge, nothing else.
 
 All parameters are views into ONE flat fp32 buffer in ``parameters()`` order (so the optimizer and
 the data-parallel gradient all-reduce see a single contiguous tensor); gradients come back the same
-way.  There is no CPU path: calling the module on a CPU tensor raises.
+way.  There is no CPU compute path: the parameters must live on a ROCm device.  A CPU *input* is accepted the way
+the reference's own inference scripts pass it (predict.py:96-101 and model_perf_aster_formatds.py:182-203 build CPU
+tensors and call ``.numpy()`` on the result): it is staged to the parameters' device, the network runs there, and the
+output comes back on the caller's device -- a transfer, not a CPU path.
 """
 from __future__ import annotations
+
+import weakref
 
 import torch
 from torch import nn
@@ -79,6 +84,19 @@ class _ModelFn(torch.autograd.Function):
         flat_p, flat_r, flat_n = module._flat_state(x.device)
         training = bool(module.training)
         need_bwd = training and any(ctx.needs_input_grad)   # grad mode is off inside forward(); this is the caller's
+        if torch.cuda.is_current_stream_capturing():
+            # a still-alive autograd graph of an EARLIER, un-captured step keeps the parameters'
+            # AccumulateGrad nodes (bound to the stream they were made on) alive; the captured backward would make torch
+            # join that stream with the capture stream and hipStreamEndCapture fails.  Refuse up front.
+            prev = module._live_node() if module._live_node is not None else None
+            if need_bwd and prev is not None and not getattr(prev, "sifsr_captured", False):
+                raise _lib.SifsrError(
+                    "stream capture of a training step while the autograd graph of an earlier (un-captured) step is still "
+                    "alive -- some tensor that requires grad (typically the previous step's loss) still references it. "
+                    "Drop or .detach() the outputs of the earlier steps before capturing (train.GraphedTrainStep does).")
+            ctx.sifsr_captured = True
+        # training-mode forward without a backward (torch.no_grad(), frozen parameters: BN recalibration) needs only the
+        # forward part of the workspace; the library checks the size against what the call will touch
         ws_bytes = _lib.call("sifsr_model_workspace_bytes", B, H, W, 1 if need_bwd else 0)
         if ws_bytes == 0:
             raise _lib.SifsrError(f"unsupported shape {tuple(x.shape)}")
@@ -99,6 +117,7 @@ class _ModelFn(torch.autograd.Function):
             ctx.x = x
             ctx.shape = (B, H, W)
             ctx.param_version = module._flat_version
+            object.__setattr__(module, "_live_node", weakref.ref(ctx))
         return sr
 
     @staticmethod
@@ -169,6 +188,7 @@ class ModelB_2(nn.Module):
         object.__setattr__(self, "_flat", None)          # (params, running, nbt) tensors; not registered
         object.__setattr__(self, "_flat_version", 0)
         object.__setattr__(self, "_last_flat_grad", None)
+        object.__setattr__(self, "_live_node", None)     # weakref to the autograd node of the last training forward
         off, slices = 0, []
         for p in self.parameters():
             slices.append((off, p.numel(), tuple(p.shape)))
@@ -185,7 +205,7 @@ class ModelB_2(nn.Module):
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("_flat", "_flat_version", "_last_flat_grad", "_param_slices", "_n_params", "_bns", "_bn_hyper"):
+        for k in ("_flat", "_flat_version", "_last_flat_grad", "_live_node", "_param_slices", "_n_params", "_bns", "_bn_hyper"):
             state.pop(k, None)
         return state
 
@@ -252,7 +272,20 @@ class ModelB_2(nn.Module):
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, x_lst_ndvi):
         """model.py:608-645: (B,2,H,W) = cat(lst_up, ndvi) -> (B,1,H,W) super-resolved LST."""
-        if not x_lst_ndvi.is_cuda:
-            raise _lib.SifsrError("ModelB_2 (MI355X build) has no CPU path: move the model and the input to a ROCm device")
-        x = x_lst_ndvi.contiguous().float()
-        return _ModelFn.apply(self, x, *self.parameters())
+        home = x_lst_ndvi.device
+        pdev = next(self.parameters()).device
+        if pdev.type != "cuda":
+            raise _lib.SifsrError("ModelB_2 (MI355X build) has no CPU compute path: the parameters are on "
+                                  f"{pdev}; call model.to('cuda') (predict.py: --prediction_device cuda)")
+        x = x_lst_ndvi
+        if home != pdev:
+            # the reference's inference scripts hand over CPU tensors (predict.py:96-100) and read the result with
+            # .numpy() (:101): stage the input to the parameters' device, bring the output back.  Inference only --
+            # a training graph across the copy would hide the device mismatch the reference itself raises on.
+            if torch.is_grad_enabled() and self.training:
+                raise _lib.SifsrError(f"training-mode input on {home} but the parameters are on {pdev}: move the batch "
+                                      "with .to(device) as train_model_B_gradFTM.py:89 does")
+            x = x.to(pdev)
+        x = x.contiguous().float()
+        sr = _ModelFn.apply(self, x, *self.parameters())
+        return sr if home == pdev else sr.to(home)

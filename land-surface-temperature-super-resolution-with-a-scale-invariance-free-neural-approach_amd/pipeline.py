@@ -32,6 +32,14 @@ def prepare_tiles(lst, ndvi, stats=None, clip_ndvi=False):
     return x
 
 
+def bicubic_up4(img):
+    """``us.upsampling(img, (4, 4))`` (utils.py:163-180, cv2.resize INTER_CUBIC) for a batch (T,1,w,w) -> (T,1,4w,4w):
+    the resampler of ``prepare_tiles`` alone (unit statistics, the NDVI half of the kernel's output discarded)."""
+    T, _, w, _ = img.shape
+    ndvi = torch.zeros((T, 1, 4 * w, 4 * w), dtype=torch.float32, device=img.device)
+    return prepare_tiles(img.contiguous(), ndvi)[:, 0:1]
+
+
 def granule_to_tiles(lst_g, ndvi_g, stats, window=64, clip_ndvi=True):
     """Raw granule rasters lst_g (h,w) [K] and ndvi_g (4h,4w) -> (x (T,2,4win,4win), (tiles_y, tiles_x)) for the
     non-overlapping full tiles of predict.py:84-95 (ragged edge tiles are skipped, as in the reference)."""

@@ -139,6 +139,8 @@ def _conv3x3_rep(x, w, b=None):
 # sign of a handful of |z| < 1e-6 pre-activations; each such flip moves a gradient by ~1/sqrt(N) of
 # its norm, so gradient parity is only meaningful at equal masks.
 RELU_MASKS = None
+# Test hook: when a dict, every _bn_relu call stores the mask it took, {bn prefix: (z > 0)}.
+RECORD_MASKS = None
 
 
 def _bn_relu(x, sd, bn, training):
@@ -148,6 +150,8 @@ def _bn_relu(x, sd, bn, training):
                      training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
     if training:
         sd[bn + ".num_batches_tracked"] += 1
+    if RECORD_MASKS is not None:
+        RECORD_MASKS[bn] = (y > 0).detach()
     if RELU_MASKS is not None:
         return y * RELU_MASKS[bn].to(y.dtype)
     return F.relu(y)

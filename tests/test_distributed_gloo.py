@@ -33,18 +33,50 @@ def _worker(rank, world, port, q):
     m = _FakeModel(n)
     g = torch.full((n,), float(rank + 1))
     m._g = g
+    m.w.grad = g.view_as(m.w)                        # what autograd does when p.grad was None: adopt the view
 
     class Opt:
         grad_scale = 1.0
     opt = Opt()
+    assert dp.grads_alias_flat(m, g)
     dp.allreduce_gradients(m, opt)
     ok = bool(torch.all(g == sum(range(1, world + 1)))) and opt.grad_scale == 1.0 / world
-    g2 = torch.full((n,), float(rank + 1)); m._g = g2
+    g2 = torch.full((n,), float(rank + 1)); m._g = g2; m.w.grad = g2.view_as(m.w)
     dp.allreduce_gradients(m, None)                  # no FlatAdam: mean applied here
     ok = ok and bool(torch.allclose(g2, torch.full((n,), sum(range(1, world + 1)) / world)))
+    # p.grad does NOT alias the last backward's buffer (zero_grad(set_to_none=False) / accumulation): the optimizer
+    # steps on p.grad, so p.grad is what must come back reduced -- reducing only flat_grad() would be silently wrong
+    stale = torch.full((n,), 100.0 * (rank + 1)); m._g = stale
+    m.w.grad = torch.full((n,), float(rank + 1))
+    assert not dp.grads_alias_flat(m, stale)
+    dp.allreduce_gradients(m, None)
+    ok = ok and bool(torch.allclose(m.w.grad, torch.full((n,), sum(range(1, world + 1)) / world)))
+    opt2 = Opt(); m.w.grad = torch.full((n,), float(rank + 1))
+    dp.allreduce_gradients(m, opt2)
+    ok = ok and bool(torch.all(m.w.grad == sum(range(1, world + 1)))) and opt2.grad_scale == 1.0 / world
+    m.w.grad = None
+    try:
+        dp.allreduce_gradients(m, None); ok = False
+    except RuntimeError:
+        pass
     m.running.fill_(float(rank))
     dp.broadcast_buffers(m, src=0)
     ok = ok and bool(torch.all(m.running == 0))
+    # replicas seeded differently (or a checkpoint loaded on one rank only) are made identical by broadcast_parameters,
+    # optimizer moments and step count included
+    torch.manual_seed(100 + rank)
+    m2 = _FakeModel(64); m2.w.data.normal_(); m2.running.normal_()
+
+    class FakeAdam:
+        capturable = False
+        def __init__(self):
+            self._m, self._v, self._step, self._step_dev = torch.randn(64), torch.rand(64), 3 + rank, None
+    o2 = FakeAdam()
+    dp.broadcast_parameters(m2, o2, src=0)
+    torch.manual_seed(100)
+    exp = _FakeModel(64); exp.w.data.normal_(); exp.running.normal_(); exp_m, exp_v = torch.randn(64), torch.rand(64)
+    ok = ok and torch.equal(m2.w.data, exp.w.data) and torch.equal(m2.running, exp.running)
+    ok = ok and torch.equal(o2._m, exp_m) and torch.equal(o2._v, exp_v) and o2._step == 3
     lo, hi = dp.shard_range(324, rank, world)
     t = torch.tensor([hi - lo]); dist.all_reduce(t)
     ok = ok and int(t) == 324
@@ -77,6 +109,6 @@ def test_world_size_2_gloo():
 
 def test_world_size_1_is_noop():
     from sifsr import distributed as dp
-    m = _FakeModel(8); m._g = torch.ones(8)
+    m = _FakeModel(8); m._g = torch.ones(8); m.w.grad = m._g.view_as(m.w)
     dp.allreduce_gradients(m, None)
     assert torch.all(m._g == 1) and dp.world_size() == 1

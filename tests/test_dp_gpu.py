@@ -1,6 +1,10 @@
 """Data-parallel step on the GPU (SURVEY.md §8 e): two ranks (gloo rehearsal on ONE device -- RCCL needs one GPU
 per rank, the 8-GPU run is the driver's) must end up with identical parameters, equal to a single-process run
-that processes the same two micro-batches with per-micro-batch BatchNorm statistics and averaged gradients."""
+that processes the same two micro-batches with per-micro-batch BatchNorm statistics and averaged gradients.
+
+Covered: SR2 and SR1 losses; replicas that were seeded DIFFERENTLY and are made identical by
+``dp.broadcast_parameters``; the ``zero_grad(set_to_none=False)`` path in which ``p.grad`` does not alias the
+backward's flat buffer (the all-reduce must then act on ``p.grad``); ``dp.broadcast_buffers`` before a save."""
 import os
 import subprocess
 import sys
@@ -16,30 +20,53 @@ import os, sys, torch
 sys.path.insert(0, os.environ["SIFSR_ROOT"])
 import sifsr
 from sifsr import distributed as dp
+kind, keep_grads = os.environ["SIFSR_KIND"], os.environ["SIFSR_KEEP_GRADS"] == "1"
+alpha, gamma = (0.5, -0.25) if kind == "sr2" else (0.99, -0.5)
 rank, world, local = dp.init_from_env()
 dev = torch.device("cuda", local)
 torch.cuda.set_device(dev)
-torch.manual_seed(0)
+torch.manual_seed(rank)                       # replicas start DIFFERENT; rank 0 is made authoritative below
 model = sifsr.ModelB_2(2, [16, 32, 64, 128], "replicate", "ReLU", 1, 1).to(dev)
 opt = sifsr.FlatAdam(model.parameters(), lr=1e-3)
+dp.broadcast_parameters(model, opt, src=0)
 stats = dict(sifsr.dataset.DEFAULT_STATS)
 lst, lst_up, ndvi = sifsr.dataset.synthetic_device_batch(4, dev, seed=77)
 lo, hi = dp.shard_range(4, rank, world)
-for _ in range(2):
-    sifsr.train.train_step(model, opt, lst[lo:hi].contiguous(), lst_up[lo:hi].contiguous(), ndvi[lo:hi].contiguous(), stats, 0.5, -0.25, "sr2")
+a, b, c = lst[lo:hi].contiguous(), lst_up[lo:hi].contiguous(), ndvi[lo:hi].contiguous()
+aliased = []
+for it in range(2):
+    if keep_grads:                            # the reference's own call: optimizer.zero_grad() with tensors kept
+        model.train()
+        opt.zero_grad(set_to_none=False)
+        sr = model(torch.cat((b, c), dim=1))
+        _, _, loss = sifsr.sif_loss(kind, sr, a, c, stats["mean_lst"], stats["std_lst"], alpha, gamma)
+        loss.backward()
+        aliased.append(dp.grads_alias_flat(model, model.flat_grad()))
+        dp.allreduce_gradients(model, opt)
+        opt.step()
+    else:
+        sifsr.train.train_step(model, opt, a, b, c, stats, alpha, gamma, kind)
+        aliased.append(dp.grads_alias_flat(model, model.flat_grad()))
 torch.cuda.synchronize()
 flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
-torch.save(flat, os.path.join(os.environ["SIFSR_OUT"], f"params_rank{rank}.pt"))
+run_before = model.inbloc.bloc[1].running_mean.detach().cpu().clone()
+dp.broadcast_buffers(model, src=0)
+run_after = model.inbloc.bloc[1].running_mean.detach().cpu().clone()
+torch.save({"flat": flat, "aliased": aliased, "run_before": run_before, "run_after": run_after},
+           os.path.join(os.environ["SIFSR_OUT"], f"rank{rank}.pt"))
 if world > 1:
     torch.distributed.barrier(); torch.distributed.destroy_process_group()
 '''
 
 
-def test_two_rank_step_matches_micro_batched_single_process(tmp_path):
+@pytest.mark.parametrize("kind,keep_grads", [("sr2", False), ("sr1", False), ("sr2", True)])
+def test_two_rank_step_matches_micro_batched_single_process(tmp_path, kind, keep_grads):
     import sifsr
     from sifsr import distributed as dp
-    env = dict(os.environ, SIFSR_ROOT=ROOT, SIFSR_OUT=str(tmp_path), SIFSR_DIST_BACKEND="gloo",
-               MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29533 + (0 if kind == "sr2" else 1) + (2 if keep_grads else 0)
+    env = dict(os.environ, SIFSR_ROOT=ROOT, SIFSR_OUT=str(tmp_path), SIFSR_DIST_BACKEND="gloo", SIFSR_KIND=kind,
+               SIFSR_KEEP_GRADS="1" if keep_grads else "0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     procs = []
@@ -48,13 +75,21 @@ def test_two_rank_step_matches_micro_batched_single_process(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script)], env=e))
     for p in procs:
         assert p.wait(timeout=600) == 0
-    a = torch.load(tmp_path / "params_rank0.pt", weights_only=True)
-    b = torch.load(tmp_path / "params_rank1.pt", weights_only=True)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    a, b = r0["flat"], r1["flat"]
     assert torch.equal(a, b), "ranks diverged"
+    # first step: p.grad was None -> autograd adopts the flat views (fast path); with set_to_none=False the second
+    # backward ACCUMULATES into the kept tensors, which no longer alias the new flat buffer (gather path)
+    assert r0["aliased"] == ([True, False] if keep_grads else [True, True])
+    # BN running statistics differ per rank (different shards) until broadcast_buffers makes rank 0's authoritative
+    assert not torch.equal(r0["run_before"], r1["run_before"])
+    assert torch.equal(r0["run_after"], r1["run_after"]) and torch.equal(r0["run_after"], r0["run_before"])
 
     # single process: same two micro-batches, per-micro-batch BN statistics, averaged gradients, one Adam step
+    alpha, gamma = (0.5, -0.25) if kind == "sr2" else (0.99, -0.5)
     dev = torch.device("cuda", 0)
-    torch.manual_seed(0)
+    torch.manual_seed(0)                      # rank 0's seed: broadcast_parameters made it everybody's
     model = sifsr.ModelB_2(2, [16, 32, 64, 128], "replicate", "ReLU", 1, 1).to(dev)
     opt = sifsr.FlatAdam(model.parameters(), lr=1e-3)
     stats = dict(sifsr.dataset.DEFAULT_STATS)
@@ -66,7 +101,7 @@ def test_two_rank_step_matches_micro_batched_single_process(tmp_path):
             model.train()
             opt.zero_grad(set_to_none=True)
             sr = model(torch.cat((lst_up[lo:hi], ndvi[lo:hi]), dim=1))
-            _, _, loss = sifsr.sif_loss("sr2", sr, lst[lo:hi].contiguous(), ndvi[lo:hi].contiguous(), stats["mean_lst"], stats["std_lst"], 0.5, -0.25)
+            _, _, loss = sifsr.sif_loss(kind, sr, lst[lo:hi].contiguous(), ndvi[lo:hi].contiguous(), stats["mean_lst"], stats["std_lst"], alpha, gamma)
             loss.backward()
             g = model.flat_grad().clone()
             acc = g if acc is None else acc + g
@@ -74,6 +109,6 @@ def test_two_rank_step_matches_micro_batched_single_process(tmp_path):
         opt.grad_scale = 0.5
         opt.step()
     ref = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
-    # BN running statistics differ per rank by design; the parameters must agree: the all-reduce adds the same two
-    # fp32 gradient buffers this loop adds, and every kernel is deterministic
+    # the parameters must agree: the all-reduce adds the same two fp32 gradient buffers this loop adds, and every kernel
+    # is deterministic.  (keep_grads: zero_grad(set_to_none=False) zeroes and autograd adds -> same values)
     assert torch.allclose(a, ref, rtol=0, atol=5e-6)

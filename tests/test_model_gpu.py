@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import sif_oracle as O
+from oracle.checks import OracleTrajectory as C_traj
 from tests.conftest import check_digest, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -39,7 +40,7 @@ def test_state_dict_is_reference_layout(sifsr, golden):
         with pytest.raises(NotImplementedError):
             sifsr.ModelB_2(2, **bad)
     with pytest.raises(sifsr.SifsrError):
-        m(torch.zeros(1, 2, 256, 256))          # CPU tensor: no CPU path
+        m(torch.zeros(1, 2, 256, 256))          # parameters on the CPU: no CPU compute path
 
 
 def test_eval_forward_vs_oracle_and_golden(sifsr, golden):
@@ -141,11 +142,10 @@ def test_train_forward_backward(sifsr, golden, kind):
     e_cpu = {n: rel_err(g32m[n], g64m[n]) for n in g}
     worst_hip, worst_cpu = max(e_hip.values()), max(e_cpu.values())
     print(f"[{kind}] worst grad rel err vs float64 at equal masks: HIP {worst_hip:.2e} | fp32 CPU reference path {worst_cpu:.2e}")
-    # Bar: 1e-4 outright, or -- where the loss gradient is smooth and BatchNorm backward cancels it to a
-    # small remainder (SR1: alpha = 0.99) -- no further from float64 than 4x the fp32 CPU path's worst tensor.
+    # Bar: 1e-4, outright, for every one of the 53 tensors (the imposed-mask mode of the oracle is pinned to the
+    # reference by tests/golden/make_golden_steps.py -> golden_masked_v1.json).
     for n in g:
-        assert e_hip[n] < max(TOL, 4 * worst_cpu), (n, e_hip[n], worst_cpu)
-    assert worst_hip < 5e-3
+        assert e_hip[n] < TOL, (n, e_hip[n], worst_cpu)
 
     # ---- gradients vs the plain fp32 oracle / the golden (reference) vectors: only a handful of ReLU
     # sign flips apart (counted here), each worth ~1/sqrt(N) of a gradient's norm -> loose bound.
@@ -165,25 +165,57 @@ def _param_step_check(t, d, atol):
         assert abs(a - b) <= atol, (a, b)
 
 
+def _golden_steps():
+    import json, os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_steps_v1.npz"))
+    return z, json.loads(bytes(z["meta_json"]).decode())
+
+
+def _check_step_update(kind, i, lr, p_before, p_after, traj_step, z, meta):
+    """HIP update of step i against (a) the oracle's elementwise update, (b) the REFERENCE's update signs on the
+    reference's significant elements (golden_steps_v1.npz)."""
+    from oracle import checks as C
+    upd_ref, p_ref, sig, _ = traj_step
+    upd = (p_after - p_before).double().cpu()
+    agree, rel_l2, n_sig = C.update_parity(upd, upd_ref, sig, p_after, p_ref, lr, i + 1, what=f"{kind} step {i}")
+    m = meta[f"{kind}_s{i}"]
+    sig_g = C.unpack_bits(z[f"{kind}_s{i}_sig"], m["n"])
+    sign_g = C.unpack_bits(z[f"{kind}_s{i}_sign"], m["n"])
+    agree_g = float(((upd > 0) == sign_g)[sig_g].double().mean())
+    l2_g = float(upd[sig_g].norm())
+    print(f"[{kind}] step {i}: update vs oracle: sign agreement {agree:.5f}, rel L2 {rel_l2:.2e} on {n_sig} significant elements; "
+          f"vs reference signs {agree_g:.5f}, |upd| {l2_g:.4e} (reference {m['upd_l2_sig']:.4e})")
+    assert agree_g >= C.MIN_SIGN_AGREE, (kind, i, agree_g)
+    assert abs(l2_g - m["upd_l2_sig"]) <= C.MAX_REL_L2 * m["upd_l2_sig"]
+
+
 @pytest.mark.parametrize("kind", ["sr2", "sr1"])
 def test_three_train_steps(sifsr, golden, kind):
     """a11 / a12: fwd + loss + bwd + Adam, three steps, against the golden (reference) trajectory.
 
-    Adam's update is ~lr*sign(g) on the first steps, so a gradient element whose sign is rounding noise
-    moves its parameter by +-lr in either implementation: parameters are compared with an absolute
-    bound of 2.5*lr per step taken, the losses (smooth in the parameters) at 2e-3 relative."""
+    Adam's update is ~lr*sign(g) on the first steps, so an absolute bound of a few lr on the parameters could not tell a
+    correct update from one with the wrong sign.  The check is on the UPDATE p_after - p_before (oracle/checks.py): on
+    the elements whose reference gradient is above the ReLU-flip noise, sign agreement >= 99.9 % and relative L2 <= 1e-2
+    against the oracle's elementwise update and against the reference's stored update signs; the +-2.5*lr*k bound is
+    kept only for the noise-level remainder.  Losses (smooth in the parameters): 1e-4 at step 1, 2e-3 after."""
     c = golden["cases"][f"train_{kind}"]
+    z, meta = _golden_steps()
     sd = O.synthetic_state(c["wseed"])
     lst, lst_up, ndvi = O.synthetic_batch(c["bseed"], c["B"])
     m = make_model(sifsr, sd)
     opt = sifsr.FlatAdam(m.parameters(), lr=c["lr"])
     stats = {"mean_lst": MEAN, "std_lst": STD}
     dl, dlu, dn = lst.cuda(), lst_up.cuda(), ndvi.cuda()
+    traj = C_traj(c, kind, MEAN, STD)
+    p_before = m.flat_parameters().detach().clone()
     for i, rec in enumerate(c["steps"]):
         ds, pl, loss = sifsr.train.train_step(m, opt, dl, dlu, dn, stats, c["alpha"], c["gamma"], kind)
         tol = TOL if i == 0 else 2e-3
         for got, key in ((ds, "ds"), (pl, "pl"), (loss, "loss")):
             assert abs(float(got) - rec[key]) < tol * abs(rec[key]), (i, key, float(got), rec[key])
+        p_after = m.flat_parameters().detach().clone()
+        _check_step_update(kind, i, c["lr"], p_before, p_after, traj.step(), z, meta)
+        p_before = p_after
         msd = m.state_dict()
         for n, d in rec["params_after"].items():
             _param_step_check(msd[n].cpu(), d, 2.5 * c["lr"] * (i + 1))
@@ -194,12 +226,14 @@ def test_torch_adam_and_unfused_loss_dropin(sifsr, golden):
     """The unchanged reference step: torch.optim.Adam + nn.HuberLoss + us.* functions -- only the
     model and the two utils functions are ours (train_model_B_gradFTM.py:94-121)."""
     c = golden["cases"]["train_sr2"]
+    z, meta = _golden_steps()
     sd = O.synthetic_state(c["wseed"])
     lst, lst_up, ndvi = (t.cuda() for t in O.synthetic_batch(c["bseed"], c["B"]))
     m = make_model(sifsr, sd).train()
     opt = torch.optim.Adam(m.parameters(), lr=c["lr"])
     loss_fn = torch.nn.HuberLoss(reduction="mean", delta=1.0)
     alpha, gamma = c["alpha"], c["gamma"]
+    p_before = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
     opt.zero_grad()
     sr = m(torch.cat((lst_up, ndvi), dim=1))
     down = (sifsr.downscale_LST_SR_to_LR(sr * STD + MEAN) - MEAN) / STD
@@ -213,6 +247,8 @@ def test_torch_adam_and_unfused_loss_dropin(sifsr, golden):
     rec = c["steps"][0]
     for got, key in ((ds, "ds"), (pl, "pl"), (loss, "loss")):
         assert abs(float(got) - rec[key]) < TOL * abs(rec[key])
+    p_after = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
+    _check_step_update("sr2", 0, c["lr"], p_before, p_after, C_traj(c, "sr2", MEAN, STD).step(), z, meta)
     msd = m.state_dict()
     for n, d in rec["params_after"].items():
         _param_step_check(msd[n].cpu(), d, 2.5 * c["lr"])

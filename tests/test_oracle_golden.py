@@ -83,3 +83,81 @@ def test_train_sr2(golden):
 
 def test_train_sr1(golden):
     _train_case(golden, "sr1")
+
+
+# ---- the imposed-mask mode (oracle.RELU_MASKS) and the update signs, pinned by tests/golden/make_golden_steps.py -----
+import json
+import os
+
+from oracle import checks as C
+
+_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_masked_mode_vs_reference_with_imposed_masks():
+    """The reference model run with seeded random masks imposed on its own nn.ReLU (forward hook) -- digests in
+    golden_masked_v1.json -- against oracle.RELU_MASKS on the same masks.  The masked network is smooth, so this holds on
+    any machine; the generator additionally asserted bit-equality for the reference's natural and perturbed masks."""
+    gm = json.load(open(os.path.join(_GOLD, "golden_masked_v1.json")))
+    for name, c in gm["cases"].items():
+        assert max(max(v.values()) for v in c["oracle_vs_reference_worst_rel"].values()) < 1e-6
+        lst, lst_up, ndvi = O.synthetic_batch(c["bseed"], c["B"])
+        O.RELU_MASKS = C.random_masks(c["mask_seed"], c["B"])
+        try:
+            sr, (ds, pl, loss), g = O.forward_backward(O.synthetic_state(c["wseed"]), lst, lst_up, ndvi, 307.2378, 5.5698,
+                                                       c["alpha"], c["gamma"], c["kind"])
+        finally:
+            O.RELU_MASKS = None
+        check_digest(sr, c["sr"], TOL)
+        for got, key in ((ds, "ds"), (pl, "pl"), (loss, "loss")):
+            assert abs(float(got) - c[key]) <= TOL * abs(c[key])
+        for n, d in c["grads"].items():
+            check_digest(g[n], d, TOL)
+
+
+def test_update_signs_along_the_trajectory(golden):
+    """Oracle trajectory (3 Adam steps) against the REFERENCE's update signs / significance masks
+    (golden_steps_v1.npz): the check the GPU tests apply to the HIP path, applied to the oracle itself."""
+    z = np.load(os.path.join(_GOLD, "golden_steps_v1.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    names = O.param_names()
+    for kind in ("sr2", "sr1"):
+        c = golden["cases"][f"train_{kind}"]
+        sd = O.synthetic_state(c["wseed"])
+        lst, lst_up, ndvi = O.synthetic_batch(c["bseed"], c["B"])
+        adam = O.AdamState(names, c["lr"])
+        hist = []
+        for i in range(3):
+            before = C.flat(sd, names)
+            _, _, grads = O.forward_backward(sd, lst, lst_up, ndvi, c["mean"], c["std"], c["alpha"], c["gamma"], kind)
+            adam.step(sd, grads)
+            hist.append(grads)
+            upd = C.flat(sd, names) - before
+            m = meta[f"{kind}_s{i}"]
+            n = m["n"]
+            sig_ref = C.unpack_bits(z[f"{kind}_s{i}_sig"], n)
+            sign_ref = C.unpack_bits(z[f"{kind}_s{i}_sign"], n)
+            assert int(sig_ref.sum()) == m["n_sig"]
+            agree = float(((upd > 0) == sign_ref)[sig_ref].double().mean())
+            assert agree >= 0.9999, (kind, i, agree)
+            assert abs(float(upd[sig_ref].norm()) - m["upd_l2_sig"]) <= 1e-3 * m["upd_l2_sig"]
+            sig = C.significant_mask(hist, names)
+            assert float((sig == sig_ref).double().mean()) >= 0.999
+
+
+def test_update_check_rejects_a_sign_error(golden):
+    """The step-level check must be able to fail: a first Adam step taken with the gradient's sign flipped stays within
+    2.5*lr of the reference parameters (the bound used in round 1) but is rejected by the update comparison."""
+    import pytest
+    c = golden["cases"]["train_sr2"]
+    traj = C.OracleTrajectory(c, "sr2", c["mean"], c["std"])
+    p0 = C.flat(traj.sd, traj.names)
+    upd_ref, p_ref, sig, _ = traj.step()
+    wrong = p0 - upd_ref                                   # every element moved the wrong way
+    assert float((wrong - p_ref).abs().max()) <= 2.5 * c["lr"]
+    with pytest.raises(AssertionError):
+        C.update_parity(wrong - p0, upd_ref, sig, wrong, p_ref, c["lr"], 1)
+    few = upd_ref.clone(); few[::200] *= -1                # 0.5 % of them
+    with pytest.raises(AssertionError):
+        C.update_parity(few, upd_ref, sig, p0 + few, p_ref, c["lr"], 1)
+    C.update_parity(upd_ref, upd_ref, sig, p_ref, p_ref, c["lr"], 1)
