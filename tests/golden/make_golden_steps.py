@@ -9,8 +9,10 @@ Writes
   * ``golden_steps_v1.npz`` -- for the two training cases of ``golden_v1.json`` (same seeds) and each of their three
     optimisation steps: the SIGN of the reference's parameter update ``p_after - p_before`` for all 282,705 elements
     (packed bits, parameters() order), the mask of elements whose reference gradient was >= 1e-2 * max|g| of their
-    tensor in every step so far ("significant": above the ReLU-flip noise, oracle/checks.py), and the L2 norm of the
-    reference update over that mask.  The run ASSERTS that the oracle's trajectory equals the reference's.
+    tensor in every step so far ("significant": above the ReLU-flip noise, oracle/checks.py), the subset of those
+    whose reference update is at least 0.2 * lr in size ("big": where the update's SIGN is meaningful -- from the
+    second step on Adam's update changes sign where 0.9 g_1 ~ -g_2), and the L2 norm of the reference update over
+    the significant mask.  The run ASSERTS that the oracle's trajectory equals the reference's.
   * ``golden_masked_v1.json`` -- pins ``oracle.RELU_MASKS`` (the oracle's imposed-mask mode, which the GPU tests use
     for their tight 1e-4 gradient check): the reference model itself is run with given masks imposed on its own
     (shared) ``nn.ReLU`` through a forward hook, and the masked oracle must reproduce its output, losses and all 53
@@ -84,6 +86,7 @@ def main():
             sig = C.significant_mask(grads_hist, names)
             arrays[f"{kind}_s{step}_sign"] = C.pack_bits(upd > 0)
             arrays[f"{kind}_s{step}_sig"] = C.pack_bits(sig)
+            arrays[f"{kind}_s{step}_big"] = C.pack_bits(sig & (upd.abs() >= C.SIGN_FRAC * lr))
             meta[f"{kind}_s{step}"] = {"n": int(upd.numel()), "n_sig": int(sig.sum()), "upd_l2_sig": float(upd[sig].norm()),
                                        "upd_l2": float(upd.norm()), "n_zero_update": int((upd == 0).sum())}
             print("   ", meta[f"{kind}_s{step}"])

@@ -126,8 +126,7 @@ def test_config1_one_epoch_batch8_16_pairs(sifsr):
         after_o = C.flat(sd, names)
         # significance from THIS step's gradients only: the two steps see different batches
         C.update_parity((p_after - p_before).double().cpu(), after_o - before_o, C.significant_mask([g_o], names),
-                        p_after, after_o, lr, i + 1, what=f"config1 step {i}",
-                        max_rel_l2=1e-2 if i == 0 else 5e-2, min_sign_agree=0.999 if i == 0 else 0.995)
+                        p_after, after_o, lr, i + 1, what=f"config1 step {i}")
         p_before = p_after
 
 

@@ -181,12 +181,13 @@ def _check_step_update(kind, i, lr, p_before, p_after, traj_step, z, meta):
     m = meta[f"{kind}_s{i}"]
     sig_g = C.unpack_bits(z[f"{kind}_s{i}_sig"], m["n"])
     sign_g = C.unpack_bits(z[f"{kind}_s{i}_sign"], m["n"])
-    agree_g = float(((upd > 0) == sign_g)[sig_g].double().mean())
+    big_g = C.unpack_bits(z[f"{kind}_s{i}_big"], m["n"])
+    agree_g = float(((upd > 0) == sign_g)[big_g].double().mean())
     l2_g = float(upd[sig_g].norm())
     print(f"[{kind}] step {i}: update vs oracle: sign agreement {agree:.5f}, rel L2 {rel_l2:.2e} on {n_sig} significant elements; "
           f"vs reference signs {agree_g:.5f}, |upd| {l2_g:.4e} (reference {m['upd_l2_sig']:.4e})")
     assert agree_g >= C.MIN_SIGN_AGREE, (kind, i, agree_g)
-    assert abs(l2_g - m["upd_l2_sig"]) <= C.MAX_REL_L2 * m["upd_l2_sig"]
+    assert abs(l2_g - m["upd_l2_sig"]) <= (C.MAX_REL_L2 if i == 0 else C.MAX_REL_L2_LATER) * m["upd_l2_sig"]
 
 
 @pytest.mark.parametrize("kind", ["sr2", "sr1"])
@@ -195,8 +196,8 @@ def test_three_train_steps(sifsr, golden, kind):
 
     Adam's update is ~lr*sign(g) on the first steps, so an absolute bound of a few lr on the parameters could not tell a
     correct update from one with the wrong sign.  The check is on the UPDATE p_after - p_before (oracle/checks.py): on
-    the elements whose reference gradient is above the ReLU-flip noise, sign agreement >= 99.9 % and relative L2 <= 1e-2
-    against the oracle's elementwise update and against the reference's stored update signs; the +-2.5*lr*k bound is
+    the elements whose reference gradient is above the ReLU-flip noise, sign agreement >= 99.9 % and relative L2 <= 1e-3
+    (first step; 1e-1 for the later, ill-conditioned ones -- oracle/checks.py) against the oracle's elementwise update and against the reference's stored update signs; the +-2.5*lr*k bound is
     kept only for the noise-level remainder.  Losses (smooth in the parameters): 1e-4 at step 1, 2e-3 after."""
     c = golden["cases"][f"train_{kind}"]
     z, meta = _golden_steps()

@@ -138,7 +138,8 @@ def test_update_signs_along_the_trajectory(golden):
             sig_ref = C.unpack_bits(z[f"{kind}_s{i}_sig"], n)
             sign_ref = C.unpack_bits(z[f"{kind}_s{i}_sign"], n)
             assert int(sig_ref.sum()) == m["n_sig"]
-            agree = float(((upd > 0) == sign_ref)[sig_ref].double().mean())
+            big_ref = C.unpack_bits(z[f"{kind}_s{i}_big"], n)
+            agree = float(((upd > 0) == sign_ref)[big_ref].double().mean())
             assert agree >= 0.9999, (kind, i, agree)
             assert abs(float(upd[sig_ref].norm()) - m["upd_l2_sig"]) <= 1e-3 * m["upd_l2_sig"]
             sig = C.significant_mask(hist, names)
