@@ -38,7 +38,7 @@ SIFSR_API int sifsr_layer_table(int* out, int capacity_rows);
 /* ---- ModelB_2 (model.py:533-645) ------------------------------------------------------------ */
 SIFSR_API size_t sifsr_model_workspace_bytes(int B, int H, int W, int training);
 /* Debug/test introspection: float offsets of the named workspace regions, in this order:
- * y[17] (raw conv outputs, NHWC), P[3], R[3], U[3], g[17] (dL/d relu(bn(y)) -> overwritten by dL/dy), dyB[3], gP[3], gU[3],
+ * y[17] (raw conv outputs, NHWC), P[3], R[3], U[3], g[17] (dL/d relu(bn(y)); dL/dy is not stored), dyB[3] (unused), gP[3], gU[3],
  * mean, invstd, scale, shift (per-channel vectors of all layers, indexed by ch_off).  Returns the count (56). */
 SIFSR_API int sifsr_model_workspace_regions(int B, int H, int W, size_t* out, int capacity);
 /* ModelB_2.forward, model.py:608-645.  training != 0: batch statistics, running-stat update
@@ -80,6 +80,14 @@ SIFSR_API int sifsr_conv3x3_fwd(const float* src0, int C0, const float* scale0, 
 SIFSR_API int sifsr_conv3x3_dgrad(const float* dy, int cout, const float* wdgrad, const float* w_oihw, int cin,
                                   float* g0, int C0, float* g1, int C1, const float* addend, int B, int H, int W,
                                   void* stream);
+/* The input gradient as ModelB_2's backward runs it since round 2: the layer's BatchNorm+ReLU backward (model.py:136-137)
+ * is applied while the operand is staged, dy = sc*g*[z>0] + k1*z + k0 with z = y*sc + sh, so dL/dy is never written to
+ * HBM.  g = dL/d relu(bn(y)) and y = the layer's raw conv output (both NHWC, cout channels), coef_f = [sc|sh|k1|k0] from
+ * sifsr_bn_relu_bwd_coef.  border: cout-channel NHWC scratch of the same size, only its image-border pixels are written
+ * (dL/dy there, for the replicate-padding fold). */
+SIFSR_API int sifsr_conv3x3_dgrad_fused(const float* g, const float* y, const float* coef_f, int cout, const float* wdgrad,
+                                        int cin, float* g0, int C0, float* g1, int C1, const float* addend, float* border,
+                                        int B, int H, int W, void* stream);
 /* bf16-operand forms of the two calls above (BASELINE.json config 5): operands rounded to bf16 while staging,
  * v_mfma_f32_16x16x32_bf16 (two taps per MFMA), fp32 accumulation and output.  Both take the `wdgrad` buffer of
  * sifsr_pack_conv_weights, whose second half holds the bf16 fragment packs [forward | dgrad]. */
@@ -103,6 +111,11 @@ SIFSR_API int sifsr_conv3x3_wgrad(const float* src0, int C0, const float* scale0
                                   const float* src1, int C1, const float* scale1, const float* shift1,
                                   const float* dy, int cout, float* scratch, int nblk, float* dw, int B, int H, int W,
                                   void* stream);
+/* The weight gradient with dL/dy formed while its tile is staged (see sifsr_conv3x3_dgrad_fused): g, y, coef_f as there. */
+SIFSR_API int sifsr_conv3x3_wgrad_fused(const float* src0, int C0, const float* scale0, const float* shift0,
+                                        const float* src1, int C1, const float* scale1, const float* shift1,
+                                        const float* g, const float* y, const float* coef_f, int cout, float* scratch,
+                                        int nblk, float* dw, int B, int H, int W, void* stream);
 /* bf16-operand form of the weight gradient (BASELINE.json config 5): the staged x and dy are rounded to bf16 when
  * read from LDS and contracted 16 pixels at a time with v_mfma_f32_16x16x16_bf16; fp32 accumulation and slabs. */
 SIFSR_API int sifsr_conv3x3_wgrad_bf16(const float* src0, int C0, const float* scale0, const float* shift0,
@@ -143,6 +156,13 @@ SIFSR_API int sifsr_bn_finalize(const float* stat_partials, int nblk, int C, dou
 SIFSR_API int sifsr_bn_relu_bwd(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
                                 const float* invstd, int C, size_t npix, float* partials, int nblk, float* dgamma,
                                 float* dbeta, double* coef, float* dy, const float* gpool, int H, int W, void* stream);
+/* The statistics half alone, as the model's backward uses it: dgamma, dbeta and coef_f = 4*C floats [sc | sh | k1 | k0]
+ * with which sifsr_conv3x3_dgrad_fused / _wgrad_fused form dL/dy = sc*g*[z>0] + k1*z + k0 (z = y*sc + sh) themselves; beta =
+ * the BatchNorm bias.  gpool != NULL: g is completed IN PLACE to g + 0.25*gpool[y/2][x/2] (the AvgPool2d adjoint). */
+SIFSR_API int sifsr_bn_relu_bwd_coef(float* g, const float* y, const float* scale, const float* shift, const float* mean,
+                                     const float* invstd, const float* beta, int C, size_t npix, float* partials, int nblk,
+                                     float* dgamma, float* dbeta, double* coef, float* coef_f, const float* gpool, int H, int W,
+                                     void* stream);
 
 /* ---- resampling (NHWC; scale == NULL: input used as stored) ---------------------------------- */
 SIFSR_API int sifsr_bnrelu_pool2(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W, int C, void* stream); /* AvgPool2d(2,2), model.py:504 */

@@ -75,12 +75,13 @@ __device__ __forceinline__ float4 pool_adj4(const PoolAdj pa, size_t p, int c4) 
 
 // per-workgroup partial (sum dz, sum dz*xhat) per channel
 template <int C>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* g, const float* __restrict__ y,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, size_t npix,
-                                                            float* __restrict__ partials, const PoolAdj pa) {
+                                                            float* __restrict__ partials, const PoolAdj pa,
+                                                            float* __restrict__ g_out) {
   SIFSR_CHAIN_PRIO();
   constexpr int Q = C / 4;          // channel quads
   constexpr int PP = 256 / Q;       // pixels per pass per workgroup
@@ -91,7 +92,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   for (size_t p = (size_t)blockIdx.x * PP + pl; p < npix; p += (size_t)gridDim.x * PP) {
     const float4 yv = ld4(y + p * C + 4 * c4);
     float4 gv = ld4(g + p * C + 4 * c4);
-    if (pa.gp != nullptr) { const float4 q = pool_adj4<C>(pa, p, c4); gv.x += q.x; gv.y += q.y; gv.z += q.z; gv.w += q.w; }
+    if (pa.gp != nullptr) {
+      const float4 q = pool_adj4<C>(pa, p, c4); gv.x += q.x; gv.y += q.y; gv.z += q.z; gv.w += q.w;
+      // the completed gradient goes back in place (g_out == g; each element is read and written by this thread only):
+      // the input- and weight-gradient convolutions of this layer form dL/dy from (g, y) while staging (bn_bwd4)
+      if (g_out != nullptr) st4(g_out + p * C + 4 * c4, gv);
+    }
     const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
     const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
     const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
@@ -122,11 +128,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
+// fp32 coefficients of bn_bwd4 (common.h), [sc | sh | k1 | k0] with C floats each: dy = sc*dz + k1*z + k0 on the
+// forward's own pre-activation z = fma(y, sc, sh); k1 = -invstd*dgamma/N, k0 = -sc*dbeta/N - k1*beta (float64, rounded once).
+static __device__ __forceinline__ void write_coef_f(float* coef_f, int C, int c, const float* scale, const float* shift,
+                                                    const float* invstd, const float* beta, double db, double dg, double count) {
+  if (coef_f == nullptr) return;
+  const double k1 = -(double)invstd[c] * dg / count;
+  coef_f[c] = scale[c];
+  coef_f[C + c] = shift[c];
+  coef_f[2 * C + c] = (float)k1;
+  coef_f[3 * C + c] = (float)(-(double)scale[c] * db / count - k1 * (double)beta[c]);
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
                                                               double count, const float* __restrict__ scale,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* dgamma,
-                                                              float* dbeta, double* coef) {
+                                                              float* dbeta, double* coef, const float* __restrict__ shift,
+                                                              const float* __restrict__ beta, float* coef_f) {
   SIFSR_CHAIN_PRIO();
   __shared__ double r1[256], r2[256];
   const int c = blockIdx.x, tid = threadIdx.x;
@@ -151,6 +170,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     coef[c] = (double)scale[c];
     coef[C + c] = k1;
     coef[2 * C + c] = -(double)scale[c] * db / count - k1 * (double)mean[c];
+    write_coef_f(coef_f, C, c, scale, shift, invstd, beta, db, dg, count);
   }
 }
 
@@ -161,7 +181,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __re
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, float* dgamma,
-                                                               float* dbeta, double* coef) {
+                                                               float* dbeta, double* coef, const float* __restrict__ shift,
+                                                               const float* __restrict__ beta, float* coef_f) {
   SIFSR_CHAIN_PRIO();
   __shared__ double r1[256], r2[256];
   const int c = blockIdx.x, tid = threadIdx.x;
@@ -183,6 +204,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __re
     coef[c] = (double)scale[c];
     coef[C + c] = k1;
     coef[2 * C + c] = -(double)scale[c] * db / count - k1 * (double)mean[c];
+    write_coef_f(coef_f, C, c, scale, shift, invstd, beta, db, dg, count);
   }
 }
 
@@ -242,13 +264,14 @@ int launch_bn_eval_coeffs(const float* params, const float* running, float eps, 
 
 int launch_bn_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
                          const float* invstd, int C, size_t npix, float* partials, int nblk, hipStream_t s, const float* gp,
-                         int H, int W) {
+                         int H, int W, float* g_out) {
   if (gp != nullptr && (H < 2 || W < 2 || H % 2 || W % 2 || npix % ((size_t)H * W))) return SIFSR_ERR_SHAPE;
+  if (g_out != nullptr && (g_out != g || gp == nullptr)) return SIFSR_ERR_ARG;   // in place, and only with the pooling adjoint
   const PoolAdj pa{gp, H, W};
   switch (C) {
-    case 16: hipLaunchKernelGGL((bn_bwd_reduce_kernel<16>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa); break;
-    case 32: hipLaunchKernelGGL((bn_bwd_reduce_kernel<32>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa); break;
-    case 64: hipLaunchKernelGGL((bn_bwd_reduce_kernel<64>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa); break;
+    case 16: hipLaunchKernelGGL((bn_bwd_reduce_kernel<16>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa, g_out); break;
+    case 32: hipLaunchKernelGGL((bn_bwd_reduce_kernel<32>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa, g_out); break;
+    case 64: hipLaunchKernelGGL((bn_bwd_reduce_kernel<64>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa, g_out); break;
     default: return SIFSR_ERR_SHAPE;
   }
   SIFSR_LAUNCH_CHECK();
@@ -256,17 +279,21 @@ int launch_bn_bwd_reduce(const float* g, const float* y, const float* scale, con
 }
 
 int launch_bn_bwd_finalize(const float* partials, int nblk, int C, double count, const float* scale, const float* mean,
-                           const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s) {
+                           const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s, const float* shift,
+                           const float* beta, float* coef_f) {
+  if (coef_f != nullptr && (!shift || !beta)) return SIFSR_ERR_ARG;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, partials, nblk, C, count, scale, mean, invstd,
-                     dgamma, dbeta, coef);
+                     dgamma, dbeta, coef, shift, beta, coef_f);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
 
 int launch_bn_bwd_finalize2(const float* pa, int na, const float* pb, int nb, int C, double count, const float* scale,
-                            const float* mean, const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s) {
+                            const float* mean, const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s,
+                            const float* shift, const float* beta, float* coef_f) {
+  if (coef_f != nullptr && (!shift || !beta)) return SIFSR_ERR_ARG;
   hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3(C), dim3(256), 0, s, pa, na, pb, nb, C, count, scale, mean, invstd, dgamma,
-                     dbeta, coef);
+                     dbeta, coef, shift, beta, coef_f);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

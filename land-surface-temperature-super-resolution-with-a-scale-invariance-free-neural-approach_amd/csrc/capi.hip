@@ -105,6 +105,26 @@ int sifsr_conv3x3_dgrad(const float* dy, int cout, const float* wdgrad, const fl
   return launch_dgrad_border_fix(dy, cout, wdgrad, cin, g0, C0, C0, g1 ? g1 : g0, g1 ? C1 : C0, B, H, W, S(stream));
 }
 
+// The same input gradient with the layer's BatchNorm+ReLU backward applied while staging: g = dL/d relu(bn(y)), y, coef_f
+// (sifsr_bn_relu_bwd_coef) -> dL/dy is never stored, except on the image border (`border`, cout-channel NHWC indexing).
+int sifsr_conv3x3_dgrad_fused(const float* g, const float* y, const float* coef_f, int cout, const float* wdgrad, int cin,
+                              float* g0, int C0, float* g1, int C1, const float* addend, float* border, int B, int H, int W,
+                              void* stream) {
+  if (cout % 16 || cin % 16 || C0 % 16 || (g1 && (C1 % 16 || C0 + C1 != cin)) || (!g1 && C0 != cin) || (addend && g1))
+    return SIFSR_ERR_SHAPE;
+  if (!g || !y || !coef_f || !border) return SIFSR_ERR_ARG;
+  ConvArgs a;
+  a.src[0] = mk_src(g, cout, nullptr, nullptr); a.src[1] = mk_src(nullptr, 0, nullptr, nullptr);
+  a.bw_y = y; a.bw_coef = coef_f; a.bw_border = border;
+  a.dst[0].ptr = g0; a.dst[0].C = C0; a.dst[0].coff = 0;
+  a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
+  a.wpack = wdgrad; a.addend = addend; a.addC = cin; a.stat_partials = nullptr; a.dst_split = C0 / 16;
+  a.B = B; a.H = H; a.W = W; a.NQ = cout / 16;
+  int rc = launch_conv3x3_mfma(a, cin, 1, S(stream));
+  if (rc) return rc;
+  return launch_dgrad_border_fix(border, cout, wdgrad, cin, g0, C0, C0, g1 ? g1 : g0, g1 ? C1 : C0, B, H, W, S(stream));
+}
+
 // bf16-operand forms (config 5): both bf16 packs live in the second half of the `wdgrad` buffer written by
 // sifsr_pack_conv_weights ([fp32 dgrad pack n | fwd hi n/2 | dgrad hi n/2 | fwd mid | dgrad mid | fwd lo | dgrad lo], n = 9*cin*cout floats)
 static int conv3x3_fwd_lowp(int mode, const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
@@ -168,6 +188,24 @@ int sifsr_conv3x3_wgrad(const float* src0, int C0, const float* scale0, const fl
   a.src[0] = mk_src(src0, C0, scale0, shift0);
   a.src[1] = mk_src(src1, C1, scale1, shift1);
   a.dy = dy; a.slabs = scratch; a.B = B; a.H = H; a.W = W;
+  a.NQ = a.src[0].nq + a.src[1].nq;
+  a.ntiles = B * ((H + 7) / 8) * ((W + 15) / 16);
+  const int cin = 16 * a.NQ;
+  if (nblk > a.ntiles) nblk = a.ntiles;
+  int rc = launch_conv3x3_wgrad(a, cin, cout, nblk, S(stream));
+  if (rc) return rc;
+  return launch_wgrad_reduce(scratch, nblk, cin, cout, wgrad_nbi_chunk(a, cin), dw, S(stream));
+}
+
+int sifsr_conv3x3_wgrad_fused(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
+                              const float* scale1, const float* shift1, const float* g, const float* y, const float* coef_f,
+                              int cout, float* scratch, int nblk, float* dw, int B, int H, int W, void* stream) {
+  if (!src0 || C0 % 16 || (src1 && C1 % 16)) return SIFSR_ERR_SHAPE;
+  if (!g || !y || !coef_f) return SIFSR_ERR_ARG;
+  WgradArgs a;
+  a.src[0] = mk_src(src0, C0, scale0, shift0);
+  a.src[1] = mk_src(src1, C1, scale1, shift1);
+  a.dy = g; a.dy_y = y; a.dy_coef = coef_f; a.slabs = scratch; a.B = B; a.H = H; a.W = W;
   a.NQ = a.src[0].nq + a.src[1].nq;
   a.ntiles = B * ((H + 7) / 8) * ((W + 15) / 16);
   const int cin = 16 * a.NQ;
@@ -257,6 +295,15 @@ int sifsr_bn_relu_bwd(const float* g, const float* y, const float* scale, const 
   rc = launch_bn_bwd_finalize(partials, nblk, C, (double)npix, scale, mean, invstd, dgamma, dbeta, coef, S(stream));
   if (rc) return rc;
   return launch_bn_bwd_apply(g, y, scale, shift, coef, C, npix, dy, S(stream), gpool, H, W);
+}
+
+int sifsr_bn_relu_bwd_coef(float* g, const float* y, const float* scale, const float* shift, const float* mean,
+                           const float* invstd, const float* beta, int C, size_t npix, float* partials, int nblk, float* dgamma,
+                           float* dbeta, double* coef, float* coef_f, const float* gpool, int H, int W, void* stream) {
+  if (!g || !y || !beta || !coef || !coef_f) return SIFSR_ERR_ARG;
+  int rc = launch_bn_bwd_reduce(g, y, scale, shift, mean, invstd, C, npix, partials, nblk, S(stream), gpool, H, W, gpool ? g : nullptr);
+  if (rc) return rc;
+  return launch_bn_bwd_finalize(partials, nblk, C, (double)npix, scale, mean, invstd, dgamma, dbeta, coef, S(stream), shift, beta, coef_f);
 }
 
 int sifsr_bnrelu_pool2(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W, int C, void* stream) {

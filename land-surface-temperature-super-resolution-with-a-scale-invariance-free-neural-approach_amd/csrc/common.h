@@ -46,6 +46,25 @@ static __device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh
   return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 
+// BatchNorm + ReLU BACKWARD applied while a consumer stages its operand (the input-gradient and weight-gradient
+// convolutions of layer l read g_l = dL/d relu(bn(y_l)) and y_l instead of a stored dL/dy_l):
+//   z  = fma(y, sc, sh)                      the forward's pre-activation, bit for bit (same fma) -> same ReLU mask
+//   dy = sc * (z > 0 ? g : 0) + k1 * z + k0
+// with sc = gamma*invstd, sh = beta - mean*sc, k1 = -invstd * sum(dz*xhat) / N, k0 = -sc * sum(dz) / N - k1 * beta
+// (bn_bwd_finalize*_kernel; nn.BatchNorm2d backward, model.py:136-137: dy = sc * (dz - mean(dz) - xhat * mean(dz*xhat)),
+// xhat = (z - beta) / gamma -- written on z so that no division by gamma appears and gamma = 0 gives dy = 0).
+static __device__ __forceinline__ float4 bn_bwd4(float4 g, float4 y, float4 sc, float4 sh, float4 k1, float4 k0) {
+  f32x2 zl = __builtin_elementwise_fma((f32x2){y.x, y.y}, (f32x2){sc.x, sc.y}, (f32x2){sh.x, sh.y});
+  f32x2 zh = __builtin_elementwise_fma((f32x2){y.z, y.w}, (f32x2){sc.z, sc.w}, (f32x2){sh.z, sh.w});
+  const f32x2 tl = __builtin_elementwise_fma((f32x2){k1.x, k1.y}, zl, (f32x2){k0.x, k0.y});
+  const f32x2 th = __builtin_elementwise_fma((f32x2){k1.z, k1.w}, zh, (f32x2){k0.z, k0.w});
+  const f32x2 dl = {zl.x > 0.f ? g.x : 0.f, zl.y > 0.f ? g.y : 0.f};
+  const f32x2 dh = {zh.x > 0.f ? g.z : 0.f, zh.y > 0.f ? g.w : 0.f};
+  const f32x2 ol = __builtin_elementwise_fma((f32x2){sc.x, sc.y}, dl, tl);
+  const f32x2 oh = __builtin_elementwise_fma((f32x2){sc.z, sc.w}, dh, th);
+  return make_float4(ol.x, ol.y, oh.x, oh.y);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Network table (== reference state_dict order, model.py:596-605; checked by tests/test_capi_symbols.py)
 // ---------------------------------------------------------------------------------------------

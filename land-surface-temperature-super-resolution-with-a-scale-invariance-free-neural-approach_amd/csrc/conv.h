@@ -37,6 +37,13 @@ struct ConvArgs {
   const float* bn_y = nullptr;
   const float* bn_scale = nullptr;
   const float* bn_shift = nullptr;
+  // dgrad with the BatchNorm+ReLU backward of ITS OWN layer applied while staging (bn_bwd4, common.h): src[0].ptr is
+  // g = dL/d relu(bn(y)) (C = the layer's cout), bw_y the layer's raw conv output, bw_coef = [sc | sh | k1 | k0], C floats
+  // each (bn_bwd_finalize*).  dL/dy is then never stored -- except on the image border, where the producers also write it
+  // to bw_border (same NHWC indexing, only border pixels are touched) for the replicate-border fold kernel.
+  const float* bw_y = nullptr;
+  const float* bw_coef = nullptr;
+  float* bw_border = nullptr;
 };
 
 // conv3x3, stride 1, NHWC fp32, MFMA implicit GEMM.  zero_pad = 0: replicate padding (forward,
@@ -53,6 +60,10 @@ struct WgradArgs {
   int NQ;              // Cin / 16 (total)
   int ntiles;          // B * ceil(H/8) * ceil(W/16)
   int bf16 = 0;        // 1: operands rounded to bf16 when read from LDS, v_mfma_f32_16x16x16_bf16 (config 5)
+  // dy_y != nullptr: `dy` is g = dL/d relu(bn(y)) and dL/dy is formed while staging (bn_bwd4): dy_y = the layer's raw
+  // conv output, dy_coef = [sc | sh | k1 | k0] (Cout floats each)
+  const float* dy_y = nullptr;
+  const float* dy_coef = nullptr;
 };
 // returns the number of slab blocks used through *nblk_out
 int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s);

@@ -101,9 +101,12 @@ static __device__ __forceinline__ uint2 bload2(__amdgpu_buffer_rsrc_t r, unsigne
 // exactly into three bf16 terms while staging (x = hi + mid + lo) and six of the nine cross products are accumulated
 // (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are <= 2^-24 relative, the size of one fp32 rounding):
 // six v_mfma_f32_16x16x32_bf16 (16 cycles each, two taps per MFMA) replace eight v_mfma_f32_16x16x4_f32 (32 cycles each) per 16 channels.
-template <int NB, bool ZERO_PAD, int MODE>
+// DYF (dgrad only): the operand is dL/dy of the layer, formed while staging from g = dL/d relu(bn(y)) and y
+// (bn_bwd4) -- the BatchNorm-backward elementwise pass and its tensor round trip do not exist (ConvArgs::bw_*).
+template <int NB, bool ZERO_PAD, int MODE, bool DYF>
 __global__ __launch_bounds__(512, (NB <= 2 && MODE != 2 ? 4 : 2)) void conv3x3_mfma_kernel(const ConvArgs a, const int ntiles, const int lgx,
                                                            const int lgy) {
+  static_assert(!DYF || ZERO_PAD, "the fused BatchNorm backward belongs to the input-gradient pass");
   constexpr bool BF16 = MODE != 0, X3 = MODE == 2;
   // X3 with 2 or 4 cout blocks: TWO adjacent blocks per wave and half the rows, so every operand word read from LDS
   // feeds twice the MFMAs (at 16 cycles per bf16 MFMA and three operand planes the one-block tiling is LDS-bound)
@@ -146,6 +149,8 @@ __global__ __launch_bounds__(512, (NB <= 2 && MODE != 2 ? 4 : 2)) void conv3x3_m
     // =========================================== PRODUCER ===========================================
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.src[0].ptr, npix * a.src[0].C * 4u);
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.src[1].ptr ? a.src[1].ptr : a.src[0].ptr, npix * (a.src[1].ptr ? a.src[1].C : a.src[0].C) * 4u);
+    const __amdgpu_buffer_rsrc_t rsy = make_rsrc(DYF ? a.bw_y : a.src[0].ptr, npix * a.src[0].C * 4u);
+    const __amdgpu_buffer_rsrc_t rbd = make_rsrc(DYF && a.bw_border ? a.bw_border : const_cast<float*>(a.src[0].ptr), npix * a.src[0].C * 4u);
     // staging map: thread -> (channel quad cg, 6 halo pixels).  Interior tiles: the 6 pixel offsets relative to
     // the halo origin are tile-independent constants; the tile position is a SCALAR offset.
     const int ptid = tid - 256;
@@ -188,10 +193,13 @@ __global__ __launch_bounds__(512, (NB <= 2 && MODE != 2 ? 4 : 2)) void conv3x3_m
     // consumers work on item j.  (Two register sets / two items in flight measured 4 % slower: the consumers,
     // not the load latency, are the critical path.)
     float4 stgA[6], scA, shA;
+    float4 styA[DYF ? 6 : 1], k1A = make_float4(0.f, 0.f, 0.f, 0.f), k0A = k1A;   // DYF: y of the same slots, two more coefficient quads
     bool rawA = true;
     int it_t = t, it_q = 0;       // next item to fetch; past the end the last item is fetched again (never used)
+    int tA = t, qA = 0;           // DYF: (tile, channel block) of the item held in stgA (for the masks of write_stage)
     auto issue_loads = [&](float4 (&stg)[6], float4& psc, float4& psh, bool& praw) {
       const int q = it_q;
+      if (DYF) { tA = it_t; qA = it_q; }
       const bool first = q < a.src[0].nq;
       const int C = first ? a.src[0].C : a.src[1].C;
       const int lgc = 31 - __builtin_clz((unsigned)C) + 2;                       // log2(C * 4 bytes)
@@ -202,21 +210,49 @@ __global__ __launch_bounds__(512, (NB <= 2 && MODE != 2 ? 4 : 2)) void conv3x3_m
       for (int it = 0; it < 6; ++it) {
         const unsigned voff = (ZERO_PAD && pixv[it] < 0) ? OOB : (((unsigned)pixv[it] << lgc) + (unsigned)cg * 16u);
         stg[it] = bload4(r, voff, soff);
+        if (DYF) styA[it] = bload4(rsy, voff, soff);
       }
       const float* scp = first ? a.src[0].scale : a.src[1].scale;
       const float* shp = first ? a.src[0].shift : a.src[1].shift;
       praw = scp == nullptr;
       const int chs = praw ? 0 : ch + 4 * cg;
-      psc = ld4((praw ? a.wpack : scp) + chs); psh = ld4((praw ? a.wpack : shp) + chs);   // unconditional: fixed load count per set
+      if (DYF) {   // [sc | sh | k1 | k0], C floats each
+        psc = ld4(a.bw_coef + ch + 4 * cg); psh = ld4(a.bw_coef + C + ch + 4 * cg);
+        k1A = ld4(a.bw_coef + 2 * C + ch + 4 * cg); k0A = ld4(a.bw_coef + 3 * C + ch + 4 * cg);
+      } else {
+        psc = ld4((praw ? a.wpack : scp) + chs); psh = ld4((praw ? a.wpack : shp) + chs);   // unconditional: fixed load count per set
+      }
       // advance to the next item
       if (it_q + 1 < NQ) ++it_q;
       else if (it_t + t_step < t_hi) { it_t += t_step; it_q = 0; set_tile(it_t); }
     };
     auto write_stage = [&](float4* Lb, const float4 (&stg)[6], const float4 psc, const float4 psh, const bool praw) {
+      // DYF: tile of THIS item (the tile state above already belongs to the next one).  Halo pixels outside the image
+      // are zero padding of dL/dy (bn_bwd4 of the zeros they loaded is not 0), and the image-border pixels of the tile's
+      // own 16x16 core go to bw_border for the border-fold kernel.  Interior tiles need neither.
+      int wb = 0, wy0 = 0, wx0 = 0;
+      bool winterior = true;
+      if (DYF) {
+        int txi, tyi;
+        tile_pos(tA, wb, txi, tyi);
+        wy0 = tyi * 16 - 1; wx0 = txi * 16 - 1;
+        winterior = txi > 0 && tyi > 0 && txi + 1 < tiles_x && tyi + 1 < tiles_y;
+      }
 #pragma unroll
       for (int it = 0; it < 6; ++it) {
         float4 v = stg[it];
-        if (!praw) v = bn_relu4(v, psc, psh);
+        if (DYF) {
+          v = bn_bwd4(v, styA[it], psc, psh, k1A, k0A);
+          if (!winterior) {
+            const int gy = wy0 + spy[it], gx = wx0 + spx[it];
+            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool core = spy[it] >= 1 && spy[it] <= 16 && spx[it] >= 1 && spx[it] <= 16;
+            const bool edge = gy == 0 || gy == H - 1 || gx == 0 || gx == W - 1;
+            if (a.bw_border != nullptr && inside && core && edge && (it < 5 || pslot < PW * PW - 320))
+              bstore4(rbd, (unsigned)((wb * H + gy) * W + gx) * (unsigned)a.src[0].C * 4u + (unsigned)(16 * qA + 4 * cg) * 4u, 0u, v);
+          }
+        } else if (!praw) v = bn_relu4(v, psc, psh);
         if (it < 5 || pslot < PW * PW - 320) {
           if (X3) {
             uint2 hi, mid, lo;
@@ -763,12 +799,18 @@ int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s
   if (!pow2(a.src[0].C) || (a.src[1].ptr && !pow2(a.src[1].C))) return SIFSR_ERR_SHAPE;
   const int tx_ = (a.W + 15) / 16, ty_ = (a.H + 15) / 16;
   const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
-#define SIFSR_CONV_LAUNCH(NBV, ZP, MD) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, ZP, MD>), grid, block, 0, s, a, ntiles, lgx, lgy)
+  const bool dyf = a.bw_y != nullptr;
+  if (dyf && (!zero_pad || !a.bw_coef || a.src[1].ptr || a.src[0].scale || a.src[0].coff)) return SIFSR_ERR_ARG;
+#define SIFSR_CONV_LAUNCH(NBV, ZP, MD, DY) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, ZP, MD, DY>), grid, block, 0, s, a, ntiles, lgx, lgy)
+#define SIFSR_CONV_MODE(NBV, MD)                                                                          \
+    if (dyf) SIFSR_CONV_LAUNCH(NBV, true, MD, true);                                                      \
+    else if (zero_pad) SIFSR_CONV_LAUNCH(NBV, true, MD, false);                                           \
+    else SIFSR_CONV_LAUNCH(NBV, false, MD, false);
 #define SIFSR_CONV_CASE(NBV)                                                                              \
   case NBV:                                                                                               \
-    if (a.bf16 == 2) { if (zero_pad) SIFSR_CONV_LAUNCH(NBV, true, 2); else SIFSR_CONV_LAUNCH(NBV, false, 2); }      \
-    else if (a.bf16) { if (zero_pad) SIFSR_CONV_LAUNCH(NBV, true, 1); else SIFSR_CONV_LAUNCH(NBV, false, 1); }      \
-    else { if (zero_pad) SIFSR_CONV_LAUNCH(NBV, true, 0); else SIFSR_CONV_LAUNCH(NBV, false, 0); }                   \
+    if (a.bf16 == 2) { SIFSR_CONV_MODE(NBV, 2) }                                                          \
+    else if (a.bf16) { SIFSR_CONV_MODE(NBV, 1) }                                                          \
+    else { SIFSR_CONV_MODE(NBV, 0) }                                                                      \
     break;
   switch (nb) {
     SIFSR_CONV_CASE(1)
@@ -778,6 +820,7 @@ int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s
     default: return SIFSR_ERR_SHAPE;
   }
 #undef SIFSR_CONV_CASE
+#undef SIFSR_CONV_MODE
 #undef SIFSR_CONV_LAUNCH
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;

@@ -41,7 +41,9 @@ static __device__ __forceinline__ wg_s16x4 wg_pack4(float a, float b, float c, f
   return __builtin_bit_cast(wg_s16x4, u);
 }
 
-template <int NBO, int NBI, bool BF16>   // cout blocks, cin blocks handled by one workgroup (cin chunk = blockIdx.y)
+// DYF: a.dy holds g = dL/d relu(bn(y)); dL/dy is formed while the dy tile is staged (bn_bwd4, common.h) from g, the
+// layer's raw conv output a.dy_y and the coefficients a.dy_coef -- the BatchNorm-backward elementwise pass is gone.
+template <int NBO, int NBI, bool BF16, bool DYF>   // cout blocks, cin blocks handled by one workgroup (cin chunk = blockIdx.y)
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, const int lgx, const int lgy) {
   constexpr int WO = NBO >= 2 ? 2 : 1, WI = NBI >= 2 ? 2 : 1, WP = 4 / (WO * WI);
   constexpr int NBO_W = NBO / WO, NBI_W = NBI / WI;
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
   const int lgc = 31 - __builtin_clz((unsigned)src.C) + 2;                 // log2(C * 4 bytes)
   const __amdgpu_buffer_rsrc_t rin = wg_rsrc(src.ptr, npix * (unsigned)src.C * 4u);
   const __amdgpu_buffer_rsrc_t rdy = wg_rsrc(a.dy, npix * (unsigned)Cout * 4u);
+  const __amdgpu_buffer_rsrc_t rdyy = wg_rsrc(DYF ? a.dy_y : a.dy, npix * (unsigned)Cout * 4u);
 
   // ---- per-thread staging constants (tile independent) ----
   const int c4o = tid % QO, po0 = tid / QO;      // dy: pixel po0 + i*PPO, channels 4*c4o..
@@ -103,7 +106,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
 #pragma unroll
       for (int t = 0; t < 9; ++t) acc[o][i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float4 pdy[NIO], pin[NII];
+  // DYF: the thread's four coefficient quads (its channels 4*c4o.. of the layer's Cout never change)
+  float4 dsc = make_float4(0.f, 0.f, 0.f, 0.f), dsh = dsc, dk1 = dsc, dk0 = dsc;
+  if (DYF) {
+    dsc = ld4(a.dy_coef + 4 * c4o); dsh = ld4(a.dy_coef + Cout + 4 * c4o);
+    dk1 = ld4(a.dy_coef + 2 * Cout + 4 * c4o); dk0 = ld4(a.dy_coef + 3 * Cout + 4 * c4o);
+  }
+  float4 pdy[NIO], pin[NII], pyy[DYF ? NIO : 1];
   auto issue = [&](int tile) {
     int txi, tyi, b;
     if (lgx >= 0) { txi = tile & (tiles_x - 1); tyi = (tile >> lgx) & (tiles_y - 1); b = tile >> (lgx + lgy); }
@@ -112,7 +121,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
     const unsigned base = (unsigned)((b * H + y0) * W + x0);
     if (x0 + 16 <= W && y0 + WT_ROWS <= H) {
 #pragma unroll
-      for (int i = 0; i < NIO; ++i) pdy[i] = wg_bload4(rdy, vo_dy[i], base * (unsigned)(Cout * 4));
+      for (int i = 0; i < NIO; ++i) {
+        pdy[i] = wg_bload4(rdy, vo_dy[i], base * (unsigned)(Cout * 4));
+        if (DYF) pyy[i] = wg_bload4(rdyy, vo_dy[i], base * (unsigned)(Cout * 4));
+      }
     } else {
       // partial tile: dy of the pixels outside the image must read as 0 (they contribute nothing to dW):
       // a per-lane offset beyond the descriptor's range makes the buffer load return 0
@@ -121,6 +133,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
         const int p = po0 + i * PPO;
         const bool in = y0 + (p >> 4) < H && x0 + (p & 15) < W;
         pdy[i] = wg_bload4(rdy, in ? vo_dy[i] : 0xFFFFFF00u, base * (unsigned)(Cout * 4));
+        if (DYF) pyy[i] = wg_bload4(rdyy, in ? vo_dy[i] : 0xFFFFFF00u, base * (unsigned)(Cout * 4));
       }
     }
     const bool interior = txi > 0 && tyi > 0 && txi + 1 < tiles_x && tyi + 1 < tiles_y;
@@ -148,6 +161,23 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
 
   while (tile < a.ntiles) {
     __syncthreads();          // previous tile's MFMA reads are done
+    if (DYF) {
+      // partial tiles: pixels outside the image loaded zeros, and bn_bwd4(0, 0) is not 0 -> mask them
+      int txi, tyi;
+      if (lgx >= 0) { txi = tile & (tiles_x - 1); tyi = (tile >> lgx) & (tiles_y - 1); }
+      else { txi = tile % tiles_x; tyi = (tile / tiles_x) % tiles_y; }
+      const int x0 = txi * 16, y0 = tyi * WT_ROWS;
+      const bool full = x0 + 16 <= W && y0 + WT_ROWS <= H;
+#pragma unroll
+      for (int i = 0; i < NIO; ++i) {
+        float4 v = bn_bwd4(pdy[i], pyy[i], dsc, dsh, dk1, dk0);
+        if (!full) {
+          const int p = po0 + i * PPO;
+          if (!(y0 + (p >> 4) < H && x0 + (p & 15) < W)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        pdy[i] = v;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NIO; ++i)
       *reinterpret_cast<float4*>(&lds_dy[(po0 + i * PPO) * CSO + 4 * c4o]) = pdy[i];
@@ -346,13 +376,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const float* 
   }
 }
 
-template <int NBO, int NBI, bool BF16>
+template <int NBO, int NBI, bool BF16, bool DYF>
 int launch_wgrad_t(const WgradArgs& a, int chunks, int nblk, hipStream_t s) {
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
   auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
   const int tx_ = (a.W + 15) / 16, ty_ = (a.H + WT_ROWS - 1) / WT_ROWS;
   const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<NBO, NBI, BF16>), dim3(nblk, chunks), dim3(256), 0, s, a, lgx, lgy);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<NBO, NBI, BF16, DYF>), dim3(nblk, chunks), dim3(256), 0, s, a, lgx, lgy);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
@@ -382,7 +412,12 @@ int launch_conv3x3_wgrad(const WgradArgs& a, int cin, int cout, int nblk, hipStr
     if (!pow2(a.src[0].C) || (a.src[1].ptr && !pow2(a.src[1].C))) return SIFSR_ERR_SHAPE;
   }
   const int nbi = wgrad_nbi_chunk(a, cin), chunks = (cin / 16) / nbi, nbo = cout / 16;
-#define SIFSR_WG(NBOV, NBIV) if (nbo == NBOV && nbi == NBIV) return a.bf16 ? launch_wgrad_t<NBOV, NBIV, true>(a, chunks, nblk, s) : launch_wgrad_t<NBOV, NBIV, false>(a, chunks, nblk, s);
+  const bool dyf = a.dy_y != nullptr;
+  if (dyf && !a.dy_coef) return SIFSR_ERR_ARG;
+#define SIFSR_WG(NBOV, NBIV)                                                                                                   \
+  if (nbo == NBOV && nbi == NBIV)                                                                                              \
+    return a.bf16 ? (dyf ? launch_wgrad_t<NBOV, NBIV, true, true>(a, chunks, nblk, s) : launch_wgrad_t<NBOV, NBIV, true, false>(a, chunks, nblk, s)) \
+                  : (dyf ? launch_wgrad_t<NBOV, NBIV, false, true>(a, chunks, nblk, s) : launch_wgrad_t<NBOV, NBIV, false, false>(a, chunks, nblk, s));
   SIFSR_WG(1, 1) SIFSR_WG(1, 2) SIFSR_WG(2, 1) SIFSR_WG(2, 2) SIFSR_WG(4, 2)
 #undef SIFSR_WG
   return SIFSR_ERR_SHAPE;

@@ -30,13 +30,19 @@ int launch_bn_finalize(const float* partials, int nblk, int C, double count, con
 int launch_bn_eval_coeffs(const float* params, const float* running, float eps, float* scale, float* shift, hipStream_t s);
 // gp != nullptr: the AvgPool2d(2,2) adjoint of the half-resolution gradient gp (image H x W at full resolution) is
 // added to g on the fly in both passes:  g_eff = g + 0.25 * gp[y/2][x/2]
+// g_out (== g, only with gp): the completed gradient g_eff is also written back in place, for consumers that form
+// dL/dy from (g, y) themselves (bn_bwd4, common.h) instead of reading the output of launch_bn_bwd_apply.
 int launch_bn_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
                          const float* invstd, int C, size_t npix, float* partials, int nblk, hipStream_t s,
-                         const float* gp = nullptr, int H = 0, int W = 0);
+                         const float* gp = nullptr, int H = 0, int W = 0, float* g_out = nullptr);
+// coef: 3 x C float64 (scale, k1, k0 of dy = scale*dz + k1*y + k0; the fused head / tail kernels and launch_bn_bwd_apply);
+// coef_f (optional, needs shift and beta): 4 x C fp32 [sc | sh | k1 | k0] of bn_bwd4 (dy = sc*dz + k1*z + k0 on z = y*sc + sh)
 int launch_bn_bwd_finalize(const float* partials, int nblk, int C, double count, const float* scale, const float* mean,
-                           const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s);
+                           const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s,
+                           const float* shift = nullptr, const float* beta = nullptr, float* coef_f = nullptr);
 int launch_bn_bwd_finalize2(const float* pa, int na, const float* pb, int nb, int C, double count, const float* scale,
-                            const float* mean, const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s);
+                            const float* mean, const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s,
+                            const float* shift = nullptr, const float* beta = nullptr, float* coef_f = nullptr);
 int launch_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, const double* coef,
                         int C, size_t npix, float* dy, hipStream_t s, const float* gp = nullptr, int H = 0, int W = 0);
 int launch_nbt_increment(long long* nbt, int n, hipStream_t s);

@@ -14,10 +14,14 @@ struct WsLayout {
   size_t P[3], R[3], U[3];                // pooled inputs, residual sums, upsampled decoder inputs
   size_t partials;                        // BN statistic partials (scratch)
   size_t fwd_end;
-  size_t coef;                            // BN-backward affine coefficients (3 x C float64, current layer)
+  size_t coef;                            // BN-backward affine coefficients (3 x C float64, current layer: fused head / tail)
+  size_t coef_f;                          // bn_bwd4 coefficients of every layer, [4][C] fp32 at 4 * ch_off (kept for the whole backward:
+                                          // the weight gradients on the second stream read them long after the chain moved on)
+  size_t dy_border;                       // dL/dy on the image border of the layer being processed (NHWC indexing, border pixels only)
   size_t bpart;                           // BN-backward sums from the dgrad border kernel ([wave][16][2])
-  size_t g[SIFSR_NUM_BN_LAYERS];          // grad w.r.t. relu(bn(y_l)), overwritten in place by dy_l
-  size_t dyB[3];                          // dy of the residual blocks' second conv
+  size_t g[SIFSR_NUM_BN_LAYERS];          // grad w.r.t. relu(bn(y_l)); dL/dy_l is formed from (g_l, y_l) by its consumers (bn_bwd4),
+                                          // stored only for ub3.convbloc.bloc.3 (fused tail)
+  size_t dyB[3];                          // (unused since dL/dy is no longer stored; = dy_border, kept for the regions table)
   size_t gP[3], gU[3];
   size_t slabs;                           // thin-layer per-workgroup partials (scratch)
   size_t slab_l[SIFSR_NUM_BN_LAYERS];     // wgrad per-workgroup partial dW of every MFMA layer (reduced together at the end)

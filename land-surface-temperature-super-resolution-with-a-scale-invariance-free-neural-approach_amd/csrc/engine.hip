@@ -5,9 +5,9 @@
 // Dataflow per Conv-BN-ReLU unit l (training):
 //   conv kernel: y_l = conv(a_in)            a_in = relu(y_prev*scale+shift) applied on load
 //                + per-workgroup (sum,sumsq) -> bn_finalize -> mean/invstd/scale/shift, running stats
-//   backward:    bn_bwd_reduce(g_l, y_l) -> bn_bwd_finalize -> dgamma, dbeta, (c1,c0)
-//                bn_bwd_apply: dy_l = scale*g_l*[z>0] + c1*y_l + c0
-//                wgrad(a_in, dy_l) -> slabs -> reduce -> dW;  dgrad(dy_l) (+ border fold) -> g of the inputs
+//   backward:    bn_bwd_reduce(g_l, y_l) [or sums from the dgrad above] -> bn_bwd_finalize -> dgamma, dbeta, (sc, sh, k1, k0)
+//                dy_l = sc*g_l*[z>0] + k1*z + k0, z = y_l*sc + sh, is NEVER stored: formed while staging (bn_bwd4) by
+//                wgrad(a_in, g_l, y_l) -> slabs -> reduce -> dW  and  dgrad(g_l, y_l) (+ border fold) -> g of the inputs
 #include "engine.h"
 
 #include <stdio.h>
@@ -100,9 +100,11 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
   w.fwd_end = off;
   if (training) {
     w.coef = take(6 * 64);   // 3 x C float64 BN-backward coefficients of the layer being processed
+    w.coef_f = take(4 * (size_t)nt.total_channels);
     w.bpart = take((size_t)dgrad_border_waves(B, H, W, 16) * 32);   // level 0 is the largest user
     for (int l = 0; l < SIFSR_NUM_BN_LAYERS; ++l) w.g[l] = take(nt.L[l].cout * N[nt.L[l].level]);
-    w.dyB[0] = take(16 * N[1]); w.dyB[1] = take(32 * N[2]); w.dyB[2] = take(64 * N[3]);
+    w.dy_border = take(16 * N[0]);   // the largest layer (16 channels at level 0 = 32 at level 1 = 64 at level 2)
+    w.dyB[0] = w.dyB[1] = w.dyB[2] = w.dy_border;
     for (int k = 0; k < 3; ++k) w.gP[k] = take(pc[k] * N[k + 1]);
     w.gU[0] = take(64 * N[2]); w.gU[1] = take(32 * N[1]); w.gU[2] = take(16 * N[0]);
     w.slabs = take(1024 * 288);   // edge-layer partials
@@ -283,45 +285,42 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
   return SIFSR_OK;
 }
 
-// BatchNorm+ReLU backward of unit l: g (grad w.r.t. relu(bn(y_l))) -> dy (grad w.r.t. y_l); dgamma/dbeta -> grads
-// gp != nullptr: g is completed on the fly by the AvgPool adjoint of the half-resolution gradient gp (bn.hip PoolAdj)
+// BatchNorm+ReLU backward of unit l, statistics half: g = dL/d relu(bn(y_l)) -> dgamma / dbeta into grads and the
+// coefficients with which the CONSUMERS of dL/dy_l (this layer's input- and weight-gradient convolutions; the fused head
+// kernel for inbloc.bloc.0) form it from (g, y_l) while staging -- the elementwise pass and dL/dy_l itself do not exist.
+// gp != nullptr: g is first completed by the AvgPool adjoint of the half-resolution gradient gp, in place (bn.hip PoolAdj).
 // fused_stats > 0: the sums were already produced by the dgrad (fused_stats = its workgroup count) + border kernel of the
 // layer above (conv_unit_dgrad with bn_layer), so the reduce pass over (g, y) is skipped.
-int bn_unit_bwd(const Ctx& c, int l, const float* g, float* dy, float* grads, const float* gp = nullptr,
-                int fused_stats = 0) {
+int bn_unit_bwd(const Ctx& c, int l, float* g, float* grads, const float* gp = nullptr, int fused_stats = 0) {
   const LayerInfo& L = c.nt.L[l];
   const int lh = c.lvH(L.level), lw = c.lvW(L.level);
-  if (fused_stats > 0) {
-    const size_t npix = c.lay.npix[L.level];
-    SIFSR_TRY(launch_bn_bwd_finalize2(c.f(c.lay.partials), fused_stats, c.f(c.lay.bpart), dgrad_border_waves(c.B, lh, lw, 16),
-                                      L.cout, (double)npix, c.scale(l), c.f(c.lay.mean) + L.ch_off,
-                                      c.f(c.lay.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
-                                      reinterpret_cast<double*>(c.f(c.lay.coef)), c.s));
-    if (dy != nullptr)
-      SIFSR_TRY(launch_bn_bwd_apply(g, c.f(c.lay.y[l]), c.scale(l), c.shift(l), reinterpret_cast<const double*>(c.f(c.lay.coef)),
-                                    L.cout, npix, dy, c.s, gp, lh, lw));
-    return SIFSR_OK;
-  }
   const size_t npix = c.lay.npix[L.level];
+  float* coef_f = c.f(c.lay.coef_f) + 4 * (size_t)L.ch_off;
+  if (fused_stats > 0) {
+    if (gp != nullptr) return SIFSR_ERR_ARG;
+    return launch_bn_bwd_finalize2(c.f(c.lay.partials), fused_stats, c.f(c.lay.bpart), dgrad_border_waves(c.B, lh, lw, 16),
+                                   L.cout, (double)npix, c.scale(l), c.f(c.lay.mean) + L.ch_off,
+                                   c.f(c.lay.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
+                                   reinterpret_cast<double*>(c.f(c.lay.coef)), c.s, c.shift(l), c.params + L.beta_off, coef_f);
+  }
   size_t nb = npix / 256;
   const int nblk = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
-  const float* y = c.f(c.lay.y[l]);
-  SIFSR_TRY(launch_bn_bwd_reduce(g, y, c.scale(l), c.shift(l), c.f(c.lay.mean) + L.ch_off, c.f(c.lay.invstd) + L.ch_off,
-                                 L.cout, npix, c.f(c.lay.partials), nblk, c.s, gp, lh, lw));
-  SIFSR_TRY(launch_bn_bwd_finalize(c.f(c.lay.partials), nblk, L.cout, (double)npix, c.scale(l), c.f(c.lay.mean) + L.ch_off,
-                                   c.f(c.lay.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
-                                   reinterpret_cast<double*>(c.f(c.lay.coef)), c.s));
-  SIFSR_TRY(launch_bn_bwd_apply(g, y, c.scale(l), c.shift(l), reinterpret_cast<const double*>(c.f(c.lay.coef)), L.cout,
-                                npix, dy, c.s, gp, lh, lw));
-  return SIFSR_OK;
+  SIFSR_TRY(launch_bn_bwd_reduce(g, c.f(c.lay.y[l]), c.scale(l), c.shift(l), c.f(c.lay.mean) + L.ch_off, c.f(c.lay.invstd) + L.ch_off,
+                                 L.cout, npix, c.f(c.lay.partials), nblk, c.s, gp, lh, lw, gp ? g : nullptr));
+  return launch_bn_bwd_finalize(c.f(c.lay.partials), nblk, L.cout, (double)npix, c.scale(l), c.f(c.lay.mean) + L.ch_off,
+                                c.f(c.lay.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
+                                reinterpret_cast<double*>(c.f(c.lay.coef)), c.s, c.shift(l), c.params + L.beta_off, coef_f);
 }
 
 // weight gradient of MFMA unit l from its forward inputs and dy
-int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy, float* grads) {
+// dy_stored: `dy` is dL/dy_l itself (ub3.convbloc.bloc.3, written by the fused tail); otherwise it is g_l and dL/dy_l is
+// formed while staging from (g_l, y_l, the coefficients bn_unit_bwd left)
+int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy, float* grads, bool dy_stored = false) {
   const LayerInfo& L = c.nt.L[l];
   WgradArgs a;
   a.src[0] = s0; a.src[1] = s1;
   a.dy = dy; a.slabs = c.f(c.lay.slab_l[l]);
+  if (!dy_stored) { a.dy_y = c.f(c.lay.y[l]); a.dy_coef = c.f(c.lay.coef_f) + 4 * (size_t)L.ch_off; }
   a.B = c.B; a.H = c.lvH(L.level); a.W = c.lvW(L.level);
   a.NQ = L.cin / 16;
   a.ntiles = c.B * ((a.H + 7) / 8) * ((a.W + 15) / 16);
@@ -353,14 +352,20 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
 // bn_layer >= 0: g0 is the complete gradient w.r.t. relu(bn(y_bn_layer)) (16 channels, no split, no addend): the kernel
 // and the border kernel also emit that layer's BatchNorm-backward sums; returns the number of partial rows through
 // *stat_rows (0 when the fusion does not apply).
+// dy_stored: as for conv_unit_wgrad.
 int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int split_ch, float* g1, int C1,
-                    const float* addend, int bn_layer = -1, int* stat_rows = nullptr) {
+                    const float* addend, int bn_layer = -1, int* stat_rows = nullptr, bool dy_stored = false) {
   const LayerInfo& L = c.nt.L[l];
   const bool fuse = bn_layer >= 0 && L.cin == 16 && C0 == 16 && split_ch == 16 && g1 == nullptr && addend == nullptr &&
                     c.nt.L[bn_layer].cout == 16 && c.nt.L[bn_layer].level == L.level;
   if (stat_rows) *stat_rows = 0;
   ConvArgs a;
   a.src[0] = src_raw(dy, L.cout); a.src[1] = src_none();
+  const float* dy_edge = dy;   // what the border-fold kernel reads (border pixels only)
+  if (!dy_stored) {
+    a.bw_y = c.f(c.lay.y[l]); a.bw_coef = c.f(c.lay.coef_f) + 4 * (size_t)L.ch_off; a.bw_border = c.f(c.lay.dy_border);
+    dy_edge = a.bw_border;
+  }
   a.dst[0].ptr = g0; a.dst[0].C = C0; a.dst[0].coff = 0;
   a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
   a.bf16 = (c.bf16 == 2 && L.cin == 128) ? 0 : c.bf16;     // see conv_unit_fwd
@@ -383,7 +388,7 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
     ProfScope ps(l, 2, c.s);
     SIFSR_TRY(launch_conv3x3_mfma(a, L.cin, 1, c.s));
   }
-  SIFSR_TRY(launch_dgrad_border_fix(dy, L.cout, wdg_f32, L.cin, g0, C0, split_ch, g1 ? g1 : g0, g1 ? C1 : C0, c.B, a.H,
+  SIFSR_TRY(launch_dgrad_border_fix(dy_edge, L.cout, wdg_f32, L.cin, g0, C0, split_ch, g1 ? g1 : g0, g1 ? C1 : C0, c.B, a.H,
                                     a.W, c.s, c.bf16 == 1 ? 1 : 0, fuse ? a.bn_y : nullptr, fuse ? a.bn_scale : nullptr,
                                     fuse ? a.bn_shift : nullptr, fuse ? c.f(c.lay.bpart) : nullptr));
   return SIFSR_OK;
@@ -508,12 +513,12 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     const int lv = 2 - k;
     const int la = dec_a[k], lb = dec_b[k], ls = dec_skip[k], ll = dec_low[k];
     // second conv of the DoubleConvolution (k == 2: dy already produced by the fused tail above)
-    if (k != 2) SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), c.f(w.g[lb]), grads));
-    SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads));
+    if (k != 2) SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), grads));
+    SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads, k == 2));
     int rows_a = 0;
-    SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), nt.L[la].cout, nt.L[lb].cin, nullptr, 0, nullptr, la, &rows_a));
+    SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), nt.L[la].cout, nt.L[lb].cin, nullptr, 0, nullptr, la, &rows_a, k == 2));
     // first conv: input = cat([U_k, relu(bn(y_skip))])
-    SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), c.f(w.g[la]), grads, nullptr, rows_a));
+    SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), grads, nullptr, rows_a));
     SIFSR_TRY(conv_unit_wgrad(c, la, src_raw(c.f(w.U[k]), uc[k]), src_act(c, ls), c.f(w.g[la]), grads));
     SIFSR_TRY(conv_unit_dgrad(c, la, c.f(w.g[la]), c.f(w.gU[k]), uc[k], uc[k], c.f(w.g[ls]), nt.L[ls].cout, nullptr));
     SIFSR_TRY(launch_up2x_bwd(c.f(w.gU[k]), c.f(w.g[ll]), B, c.lvH(lv + 1), c.lvW(lv + 1), uc[k], s));
@@ -528,15 +533,15 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     // lastconv: input R_k = P_k + relu(bn(y_b)); its gradient is both g(a_b) and part of g(P_k).
     // y_c also feeds the next pooling stage (k < 2): that AvgPool adjoint (of gP[k+1], computed in the previous
     // iteration) is folded into this BatchNorm backward instead of a separate accumulate pass over g[lc].
-    SIFSR_TRY(bn_unit_bwd(c, lc, c.f(w.g[lc]), c.f(w.g[lc]), grads, k < 2 ? c.f(w.gP[k + 1]) : nullptr));
+    SIFSR_TRY(bn_unit_bwd(c, lc, c.f(w.g[lc]), grads, k < 2 ? c.f(w.gP[k + 1]) : nullptr));
     SIFSR_TRY(conv_unit_wgrad(c, lc, src_raw(c.f(w.R[k]), pc[k]), src_none(), c.f(w.g[lc]), grads));
     int rows_b = 0, rows_a = 0;
     SIFSR_TRY(conv_unit_dgrad(c, lc, c.f(w.g[lc]), c.f(w.g[lb]), pc[k], pc[k], nullptr, 0, nullptr, lb, &rows_b));
-    // residual DoubleConvolution (g[lb] must survive as the skip gradient -> dy goes to dyB)
-    SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), c.f(w.dyB[k]), grads, nullptr, rows_b));
-    SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.dyB[k]), grads));
-    SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.dyB[k]), c.f(w.g[la]), pc[k], pc[k], nullptr, 0, nullptr, la, &rows_a));
-    SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), c.f(w.g[la]), grads, nullptr, rows_a));
+    // residual DoubleConvolution (g[lb] survives untouched: it is also the skip gradient added to gP[k] below)
+    SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), grads, nullptr, rows_b));
+    SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads));
+    SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), pc[k], pc[k], nullptr, 0, nullptr, la, &rows_a));
+    SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), grads, nullptr, rows_a));
     SIFSR_TRY(conv_unit_wgrad(c, la, src_raw(c.f(w.P[k]), pc[k]), src_none(), c.f(w.g[la]), grads));
     SIFSR_TRY(conv_unit_dgrad(c, la, c.f(w.g[la]), c.f(w.gP[k]), pc[k], pc[k], nullptr, 0, c.f(w.g[lb])));
     // AvgPool adjoint of gP[k] onto the skip gradient g[lp]: folded into the BatchNorm backward of lp (above / below)
@@ -544,7 +549,7 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   }
 
   // inbloc
-  SIFSR_TRY(bn_unit_bwd(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN3]), grads, c.f(w.gP[0])));
+  SIFSR_TRY(bn_unit_bwd(c, L_IN3, c.f(w.g[L_IN3]), grads, c.f(w.gP[0])));
   SIFSR_TRY(conv_unit_wgrad(c, L_IN3, src_act(c, L_IN0), src_none(), c.f(w.g[L_IN3]), grads));
   // that was the last MFMA layer: all 16 layers' weight-gradient slabs -> OIHW gradients, one launch.  With the second
   // stream it follows the last weight gradient there (it writes only the conv-weight regions of `grads`, which nothing
@@ -559,7 +564,7 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     const size_t npix = w.npix[0];
     const float* y = c.f(w.y[L_IN0]);
     if (rows_in0 > 0) {
-      SIFSR_TRY(bn_unit_bwd(c, L_IN0, c.f(w.g[L_IN0]), nullptr, grads, nullptr, rows_in0));
+      SIFSR_TRY(bn_unit_bwd(c, L_IN0, c.f(w.g[L_IN0]), grads, nullptr, rows_in0));
     } else {
       const size_t nb = npix / 256;
       const int nblk_r = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));

@@ -451,3 +451,94 @@ def test_fused_head_backward(L, shape):
     torch.cuda.synchronize()
     assert rel_err(dw.cpu(), gw) < TOL
     assert rel_err(dgam.cpu(), gg) < TOL and rel_err(dbet.cpu(), gb) < TOL
+
+
+# ---- BatchNorm+ReLU backward fused into the input- and weight-gradient convolutions (round 2) --------------------
+# (cin, cout, H, W, B, with_pool_adjoint)
+FUSED_CASES = [
+    (16, 16, 32, 48, 2, False),
+    (16, 16, 32, 32, 2, True),      # inbloc.bloc.3: g completed in place by the AvgPool adjoint
+    (16, 32, 16, 32, 1, True),      # db1.lastconv
+    (32, 32, 32, 32, 2, False),
+    (32, 64, 16, 16, 2, True),      # db2.lastconv
+    (64, 64, 32, 32, 1, False),
+    (64, 32, 16, 16, 2, False),     # ub1.convbloc.bloc.3
+    (128, 64, 16, 16, 1, False),    # ub1.convbloc.bloc.0
+    (32, 16, 24, 40, 2, False),     # partial tiles
+    (64, 64, 12, 20, 2, False),
+    (16, 16, 20, 36, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_bn_relu_backward_fused_into_dgrad_and_wgrad(L, case):
+    """z = relu(bn_train(conv(a))) with upstream gradient g on z: the model's backward never stores dL/dy -- it is formed
+    from (g, y) inside the staging of the input-gradient and weight-gradient convolutions (bn_bwd4).  Checked against
+    float64 autograd of the same three PyTorch ops (F.conv2d replicate, F.batch_norm training, relu), and against the
+    unfused chain of C-ABI calls (sifsr_bn_relu_bwd + sifsr_conv3x3_dgrad / _wgrad)."""
+    cin, cout, H, W, B, pool = case
+    rs = np.random.RandomState(hash(case) % 2**31)
+    a = rnd(rs, B, cin, H, W)
+    w = rnd(rs, cout, cin, 3, 3, scale=(2.0 / (9 * cin)) ** 0.5)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, cout).astype(np.float32))
+    beta = rnd(rs, cout, scale=0.5)
+    g = rnd(rs, B, cout, H, W)
+    gp = rnd(rs, B, cout, H // 2, W // 2) if pool else None
+    # float64 reference
+    a64, w64 = a.double().requires_grad_(True), w.double().requires_grad_(True)
+    ga64, be64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y64 = conv_rep(a64, w64)
+    z64 = F.relu(F.batch_norm(y64, None, None, ga64, be64, training=True, eps=1e-5))
+    g_eff = g.double() + (0.25 * gp.double().repeat_interleave(2, 2).repeat_interleave(2, 3) if pool else 0.0)
+    (dy64,) = torch.autograd.grad((z64 * g_eff).sum(), y64, retain_graph=True)
+    ga_ref, gw_ref, dgam_ref, dbet_ref = torch.autograd.grad((z64 * g_eff).sum(), [a64, w64, ga64, be64])
+
+    # device: forward conv + statistics, then the backward pieces
+    wf = torch.empty(9 * cin * cout, device="cuda"); wd = torch.empty(4 * 9 * cin * cout, device="cuda")
+    L.call("sifsr_pack_conv_weights", dev(w), cin, cout, wf, wd, S())
+    da = dev(nhwc(a))
+    y = torch.empty(B, H, W, cout, device="cuda")
+    nblk = L.call("sifsr_conv3x3_stat_blocks", B, H, W, cout)
+    part = torch.empty(nblk, cout, 2, device="cuda")
+    L.call("sifsr_conv3x3_fwd", da, cin, None, None, None, 0, None, None, wf, y, cout, part, B, H, W, S())
+    mean, invstd, scale, shift = (torch.empty(cout, device="cuda") for _ in range(4))
+    rm, rv = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")
+    L.call("sifsr_bn_finalize", part, nblk, cout, float(B * H * W), dev(gamma), dev(beta), rm, rv, 0.1, 1e-5, mean, invstd, scale, shift, S())
+    npix = B * H * W
+    nb = max(1, min(1024, npix // 256))
+    partials = torch.empty(max(nb, 1024) * cout * 2, device="cuda")
+    dgam, dbet = torch.empty(cout, device="cuda"), torch.empty(cout, device="cuda")
+    coef = torch.empty(3 * cout, dtype=torch.float64, device="cuda")
+    coef_f = torch.empty(4 * cout, device="cuda")
+    dg = dev(nhwc(g))
+    dgp = dev(nhwc(gp)) if pool else None
+    # unfused chain first (it does not modify g)
+    dy_u = torch.empty(B, H, W, cout, device="cuda")
+    L.call("sifsr_bn_relu_bwd", dg, y, scale, shift, mean, invstd, cout, npix, partials, nb, dgam, dbet, coef, dy_u, dgp, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dy_u.cpu()), dy64) < TOL
+    gin_u = torch.empty(B, H, W, cin, device="cuda")
+    L.call("sifsr_conv3x3_dgrad", dy_u, cout, wd, dev(w), cin, gin_u, cin, None, 0, None, B, H, W, S())
+    # fused
+    dgam.fill_(float("nan")); dbet.fill_(float("nan"))
+    L.call("sifsr_bn_relu_bwd_coef", dg, y, scale, shift, mean, invstd, dev(beta), cout, npix, partials, nb, dgam, dbet, coef, coef_f, dgp, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(dgam.cpu(), dgam_ref) < TOL and rel_err(dbet.cpu(), dbet_ref) < TOL
+    if pool:
+        assert rel_err(nchw(dg.cpu()), g_eff) < 1e-6       # completed in place
+    border = torch.full((B, H, W, cout), float("nan"), device="cuda")
+    gin = torch.full((B, H, W, cin), float("nan"), device="cuda")
+    L.call("sifsr_conv3x3_dgrad_fused", dg, y, coef_f, cout, wd, cin, gin, cin, None, 0, None, border, B, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(nchw(gin.cpu()), ga_ref) < TOL
+    assert rel_err(gin, gin_u) < 2e-5                      # the fp32 on-load form against the float64 stored form
+    bc = nchw(border.cpu())
+    edge = torch.zeros(H, W, dtype=torch.bool); edge[0] = edge[-1] = True; edge[:, 0] = edge[:, -1] = True
+    assert torch.isnan(bc[:, :, ~edge]).all()              # only border pixels are written ...
+    assert rel_err(bc[:, :, edge], dy64[:, :, edge]) < TOL  # ... with dL/dy
+    for nbk in (1, 7, 64):
+        scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_scratch_floats", cin, cout, nbk), device="cuda")
+        dwo = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+        L.call("sifsr_conv3x3_wgrad_fused", da, cin, None, None, None, 0, None, None, dg, y, coef_f, cout, scratch, nbk, dwo, B, H, W, S())
+        torch.cuda.synchronize()
+        assert rel_err(dwo.cpu(), gw_ref) < TOL, nbk
