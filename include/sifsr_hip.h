@@ -86,8 +86,23 @@ SIFSR_API int sifsr_conv3x3_dgrad(const float* dy, int cout, const float* wdgrad
  * sifsr_bn_relu_bwd_coef.  border: cout-channel NHWC scratch of the same size, only its image-border pixels are written
  * (dL/dy there, for the replicate-padding fold). */
 SIFSR_API int sifsr_conv3x3_dgrad_fused(const float* g, const float* y, const float* coef_f, int cout, const float* wdgrad,
-                                        int cin, float* g0, int C0, float* g1, int C1, const float* addend, float* border,
-                                        int B, int H, int W, void* stream);
+                                        const float* wwd, int cin, float* g0, int C0, float* g1, int C1, const float* addend,
+                                        float* border, int B, int H, int W, void* stream);   /* wwd: Winograd pack or NULL */
+/* Winograd F(2x2,3x3) forms of the forward and input-gradient convolutions (what ModelB_2 runs in fp32 for layers with
+ * <= 64 output channels and even H, W): the channel contraction runs on the 16 transform-domain positions of a 2x2 output
+ * patch instead of the 9 taps of each pixel -- 2.25x fewer matrix-core products, same fp32 accuracy class.  wwf / wwd =
+ * the transform-domain weights G g G^T in fragment order (16*cin*cout floats each) from sifsr_pack_conv_weights_wino; the
+ * tap packs are still passed (shapes the Winograd kernel does not take fall back to them; the border fold uses wdgrad).
+ * stat_partials rows: sifsr_conv3x3_stat_blocks_wino(). */
+SIFSR_API int sifsr_pack_conv_weights_wino(const float* w_oihw, int cin, int cout, float* wwf, float* wwd, void* stream);
+SIFSR_API int sifsr_conv3x3_stat_blocks_wino(int B, int H, int W, int cout);
+SIFSR_API int sifsr_conv3x3_fwd_wino(const float* src0, int C0, const float* scale0, const float* shift0,
+                                     const float* src1, int C1, const float* scale1, const float* shift1,
+                                     const float* wfwd, const float* wwf, float* y, int cout, float* stat_partials,
+                                     int B, int H, int W, void* stream);
+SIFSR_API int sifsr_conv3x3_dgrad_wino(const float* dy, int cout, const float* wdgrad, const float* wwd, int cin,
+                                       float* g0, int C0, float* g1, int C1, const float* addend, int B, int H, int W,
+                                       void* stream);
 /* bf16-operand forms of the two calls above (BASELINE.json config 5): operands rounded to bf16 while staging,
  * v_mfma_f32_16x16x32_bf16 (two taps per MFMA), fp32 accumulation and output.  Both take the `wdgrad` buffer of
  * sifsr_pack_conv_weights, whose second half holds the bf16 fragment packs [forward | dgrad]. */

@@ -68,13 +68,21 @@ int sifsr_model_backward_ex(const float* x, const float* dsr, const float* param
                                compute);
 }
 
-int launch_pack_weights_one(const float* w, int cin, int cout, float* wfwd, float* wdg, hipStream_t s);
+int launch_pack_weights_one(const float* w, int cin, int cout, float* wfwd, float* wdg, hipStream_t s, float* wwf = nullptr, float* wwd = nullptr);
 int sifsr_pack_conv_weights(const float* w_oihw, int cin, int cout, float* wfwd, float* wdgrad, void* stream) {
   if (cin % 16 || cout % 16) return SIFSR_ERR_SHAPE;
   return launch_pack_weights_one(w_oihw, cin, cout, wfwd, wdgrad, S(stream));
 }
 
+int sifsr_pack_conv_weights_wino(const float* w_oihw, int cin, int cout, float* wwf, float* wwd, void* stream) {
+  if (cin % 16 || cout % 16 || !w_oihw || !wwf || !wwd) return SIFSR_ERR_SHAPE;
+  return launch_pack_weights_one(w_oihw, cin, cout, nullptr, nullptr, S(stream), wwf, wwd);
+}
 int sifsr_conv3x3_stat_blocks(int B, int H, int W, int cout) { return conv3x3_grid_blocks(B, H, W, cout); }
+int sifsr_conv3x3_stat_blocks_wino(int B, int H, int W, int cout) {
+  ConvArgs a; a.B = B; a.H = H; a.W = W; a.wpack_wino = reinterpret_cast<const float*>(1);   // shape decision only
+  return conv3x3_grid_blocks(B, H, W, cout, conv3x3_use_wino(a, cout));
+}
 
 int sifsr_conv3x3_fwd(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
                       const float* scale1, const float* shift1, const float* wfwd, float* y, int cout,
@@ -87,6 +95,35 @@ int sifsr_conv3x3_fwd(const float* src0, int C0, const float* scale0, const floa
   a.wpack = wfwd; a.addend = nullptr; a.addC = 0; a.stat_partials = stat_partials; a.dst_split = cout / 16;
   a.B = B; a.H = H; a.W = W; a.NQ = a.src[0].nq + a.src[1].nq;
   return launch_conv3x3_mfma(a, cout, 0, S(stream));
+}
+
+int sifsr_conv3x3_fwd_wino(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
+                           const float* scale1, const float* shift1, const float* wfwd, const float* wwf, float* y, int cout,
+                           float* stat_partials, int B, int H, int W, void* stream) {
+  if (!src0 || !wfwd || !wwf || C0 % 16 || (src1 && C1 % 16)) return SIFSR_ERR_SHAPE;
+  ConvArgs a;
+  a.src[0] = mk_src(src0, C0, scale0, shift0);
+  a.src[1] = mk_src(src1, C1, scale1, shift1);
+  a.dst[0].ptr = y; a.dst[0].C = cout; a.dst[0].coff = 0; a.dst[1] = a.dst[0];
+  a.wpack = wfwd; a.wpack_wino = wwf; a.addend = nullptr; a.addC = 0; a.stat_partials = stat_partials; a.dst_split = cout / 16;
+  a.B = B; a.H = H; a.W = W; a.NQ = a.src[0].nq + a.src[1].nq;
+  return launch_conv3x3_mfma(a, cout, 0, S(stream));
+}
+
+int sifsr_conv3x3_dgrad_wino(const float* dy, int cout, const float* wdgrad, const float* wwd, int cin, float* g0, int C0,
+                             float* g1, int C1, const float* addend, int B, int H, int W, void* stream) {
+  if (cout % 16 || cin % 16 || C0 % 16 || (g1 && (C1 % 16 || C0 + C1 != cin)) || (!g1 && C0 != cin) || (addend && g1))
+    return SIFSR_ERR_SHAPE;
+  if (!wwd) return SIFSR_ERR_ARG;
+  ConvArgs a;
+  a.src[0] = mk_src(dy, cout, nullptr, nullptr); a.src[1] = mk_src(nullptr, 0, nullptr, nullptr);
+  a.dst[0].ptr = g0; a.dst[0].C = C0; a.dst[0].coff = 0;
+  a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
+  a.wpack = wdgrad; a.wpack_wino = wwd; a.addend = addend; a.addC = cin; a.stat_partials = nullptr; a.dst_split = C0 / 16;
+  a.B = B; a.H = H; a.W = W; a.NQ = cout / 16;
+  int rc = launch_conv3x3_mfma(a, cin, 1, S(stream));
+  if (rc) return rc;
+  return launch_dgrad_border_fix(dy, cout, wdgrad, cin, g0, C0, C0, g1 ? g1 : g0, g1 ? C1 : C0, B, H, W, S(stream));
 }
 
 int sifsr_conv3x3_dgrad(const float* dy, int cout, const float* wdgrad, const float* w_oihw, int cin, float* g0, int C0,
@@ -107,9 +144,9 @@ int sifsr_conv3x3_dgrad(const float* dy, int cout, const float* wdgrad, const fl
 
 // The same input gradient with the layer's BatchNorm+ReLU backward applied while staging: g = dL/d relu(bn(y)), y, coef_f
 // (sifsr_bn_relu_bwd_coef) -> dL/dy is never stored, except on the image border (`border`, cout-channel NHWC indexing).
-int sifsr_conv3x3_dgrad_fused(const float* g, const float* y, const float* coef_f, int cout, const float* wdgrad, int cin,
-                              float* g0, int C0, float* g1, int C1, const float* addend, float* border, int B, int H, int W,
-                              void* stream) {
+int sifsr_conv3x3_dgrad_fused(const float* g, const float* y, const float* coef_f, int cout, const float* wdgrad,
+                              const float* wwd, int cin, float* g0, int C0, float* g1, int C1, const float* addend, float* border,
+                              int B, int H, int W, void* stream) {
   if (cout % 16 || cin % 16 || C0 % 16 || (g1 && (C1 % 16 || C0 + C1 != cin)) || (!g1 && C0 != cin) || (addend && g1))
     return SIFSR_ERR_SHAPE;
   if (!g || !y || !coef_f || !border) return SIFSR_ERR_ARG;
@@ -118,7 +155,7 @@ int sifsr_conv3x3_dgrad_fused(const float* g, const float* y, const float* coef_
   a.bw_y = y; a.bw_coef = coef_f; a.bw_border = border;
   a.dst[0].ptr = g0; a.dst[0].C = C0; a.dst[0].coff = 0;
   a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
-  a.wpack = wdgrad; a.addend = addend; a.addC = cin; a.stat_partials = nullptr; a.dst_split = C0 / 16;
+  a.wpack = wdgrad; a.wpack_wino = wwd; a.addend = addend; a.addC = cin; a.stat_partials = nullptr; a.dst_split = C0 / 16;
   a.B = B; a.H = H; a.W = W; a.NQ = cout / 16;
   int rc = launch_conv3x3_mfma(a, cin, 1, S(stream));
   if (rc) return rc;

@@ -24,6 +24,8 @@ struct ConvArgs {
   ConvSrc src[2];       // channel concat [src0 | src1] (torch.cat([up, skip], 1), model.py:247)
   ConvDst dst[2];       // output channel blocks [0, dst_split) -> dst[0], the rest -> dst[1]
   const float* wpack;   // fragment-ordered weights, see pack_weights_kernel
+  const float* wpack_wino = nullptr;   // optional: the Winograd-domain pack (pack_wino_kernel) of the same weights; used instead
+                                       // of wpack where conv3x3_use_wino() holds (fp32, cout <= 64, even H and W)
   const float* addend;  // optional tensor added to dst[0] in the epilogue (residual gradient), C = addC
   float* stat_partials; // optional [conv3x3_grid_blocks()][Cout][2] per-workgroup (sum, sum of squares) of the output
   int addC;
@@ -50,7 +52,9 @@ struct ConvArgs {
 // nn.Conv2d(padding_mode='replicate'), model.py:135); zero_pad = 1: zero padding (the interior part
 // of the transposed conv used by dgrad; the replicate-border fold is dgrad_border_fix).
 int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s);
-int conv3x3_grid_blocks(int B, int H, int W, int cout);   // workgroups launched == stat_partials rows written
+bool conv3x3_use_wino(const ConvArgs& a, int cout);
+// workgroups launched == stat_partials rows written; wino = conv3x3_use_wino() of the same call
+int conv3x3_grid_blocks(int B, int H, int W, int cout, int wino = 0);
 
 struct WgradArgs {
   ConvSrc src[2];      // the conv's forward input (same description as in the forward call)
@@ -82,4 +86,5 @@ int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, i
                             float* bn_partials = nullptr);
 int dgrad_border_waves(int B, int H, int W, int Cin);   // rows of bn_partials ([wave][16][2]) the border kernel writes
 
-int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStream_t s);
+// wwf / wwd (optional): Winograd-domain packs of all layers, 16/9 of the size and offsets of wfwd
+int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStream_t s, float* wwf = nullptr, float* wwd = nullptr);

@@ -26,6 +26,11 @@ namespace {
 
 constexpr int PW = 18;        // plane width  (16 + 2 halo)
 constexpr int PLANE = 336;    // 18*18 = 324 pixels, padded to a multiple of 16 (bank rule)
+// Winograd variant (WINO, see the consumer): halo rows of WPITCH 16-byte slots, even columns in slots [0, 9), odd ones
+// in [WHALF, WHALF + 9), so that the 4 consecutive pixels of a patch row are slots {x/2, WHALF + x/2, x/2 + 1, WHALF + x/2 + 1}
+// and the 16 lanes of a read (8 patches of one patch row | 8 of the next, 2 halo rows = 2 * WPITCH slots = 640 B = 128 (mod
+// 256) further) cover all 64 banks exactly once.
+constexpr int WPITCH = 20, WHALF = 10, WPLANE = PW * WPITCH;   // 360 slots per channel quad
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -103,10 +108,13 @@ static __device__ __forceinline__ uint2 bload2(__amdgpu_buffer_rsrc_t r, unsigne
 // six v_mfma_f32_16x16x32_bf16 (16 cycles each, two taps per MFMA) replace eight v_mfma_f32_16x16x4_f32 (32 cycles each) per 16 channels.
 // DYF (dgrad only): the operand is dL/dy of the layer, formed while staging from g = dL/d relu(bn(y)) and y
 // (bn_bwd4) -- the BatchNorm-backward elementwise pass and its tensor round trip do not exist (ConvArgs::bw_*).
-template <int NB, bool ZERO_PAD, int MODE, bool DYF>
-__global__ __launch_bounds__(512, (NB <= 2 && MODE != 2 ? 4 : 2)) void conv3x3_mfma_kernel(const ConvArgs a, const int ntiles, const int lgx,
+// WINO (fp32 only): the consumers contract in the Winograd F(2x2, 3x3) domain -- per 2x2 output patch and channel
+// 16 products instead of 36 -- see the consumer branch.  One workgroup per CU (the transforms want registers).
+template <int NB, bool ZERO_PAD, int MODE, bool DYF, bool WINO>
+__global__ __launch_bounds__(512, (WINO ? 2 : (NB <= 2 && MODE != 2 ? 4 : 2))) void conv3x3_mfma_kernel(const ConvArgs a, const int ntiles, const int lgx,
                                                            const int lgy) {
   static_assert(!DYF || ZERO_PAD, "the fused BatchNorm backward belongs to the input-gradient pass");
+  static_assert(!WINO || (MODE == 0 && NB <= 4), "the Winograd consumer is fp32, up to 64 output channels");
   constexpr bool BF16 = MODE != 0, X3 = MODE == 2;
   // X3 with 2 or 4 cout blocks: TWO adjacent blocks per wave and half the rows, so every operand word read from LDS
   // feeds twice the MFMAs (at 16 cycles per bf16 MFMA and three operand planes the one-block tiling is LDS-bound)
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(512, (NB <= 2 && MODE != 2 ? 4 : 2)) void conv3x3_m
   constexpr int CST = PAIR ? 1 : 4;                          // ... block nb0 + CST * c
   constexpr int NG = PAIR ? (NB == 2 ? 4 : 8) : (NB == 1 ? 4 : (NB == 2 ? 8 : 16));   // tile rows per consumer wave
 
-  __shared__ float4 lds[2][(X3 ? 6 : 4) * PLANE];   // X3: three planes of 8 B per (pixel, channel quad)
+  __shared__ float4 lds[2][WINO ? 4 * WPLANE : (X3 ? 6 : 4) * PLANE];   // X3: three planes of 8 B per (pixel, channel quad)
   __shared__ float red[4][CBW][16][2];
 
   const int tid = threadIdx.x;
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(512, (NB <= 2 && MODE != 2 ? 4 : 2)) void conv3x3_m
     // serviced in groups of 16 contiguous lanes on a 32-dword bank row -> 16 consecutive pixels of ONE quad.
     const int cg = BF16 ? (ptid >> 4) & 3 : ptid & 3;
     const int pslot = BF16 ? ((ptid & 15) | ((ptid >> 6) << 4)) : ptid >> 2;
-    int spy[6], spx[6], prel[6];
+    int spy[6], spx[6], prel[6], lslot[6];
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
       int p = pslot + 64 * it;
@@ -166,6 +174,7 @@ __global__ __launch_bounds__(512, (NB <= 2 && MODE != 2 ? 4 : 2)) void conv3x3_m
       spy[it] = p / PW;
       spx[it] = p - spy[it] * PW;
       prel[it] = spy[it] * W + spx[it];
+      lslot[it] = WINO ? cg * WPLANE + spy[it] * WPITCH + (spx[it] & 1) * WHALF + (spx[it] >> 1) : cg * PLANE + pslot + 64 * it;
     }
     int pixv[6];                  // per-lane pixel index of the tile being fetched (-1: outside, dgrad only)
     int pix_base = 0;             // scalar pixel offset added to pixv (interior tiles)
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(512, (NB <= 2 && MODE != 2 ? 4 : 2)) void conv3x3_m
             L2[4 * PLANE + cg * PLANE + pslot + 64 * it] = mid;
             L2[8 * PLANE + cg * PLANE + pslot + 64 * it] = lo;
           } else if (BF16) reinterpret_cast<uint2*>(Lb)[cg * PLANE + pslot + 64 * it] = pack_bf16x4(v);
-          else Lb[cg * PLANE + pslot + 64 * it] = v;
+          else Lb[lslot[it]] = v;
         }
       }
     };
@@ -322,6 +331,156 @@ __global__ __launch_bounds__(512, (NB <= 2 && MODE != 2 ? 4 : 2)) void conv3x3_m
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[c][r] = s2[c][r] = 0.f;
 
+
+  if constexpr (WINO) {
+    // =================================== Winograd F(2x2, 3x3) consumer ===================================
+    // Y = A^T [ (G g G^T) . (B^T d B) ] A per 2x2 output patch: the channel contraction runs on the 16 transform-domain
+    // positions xi = (a, b) instead of the 9 taps -- 16 products per 4 outputs instead of 36 (2.25x fewer MFMAs).
+    //   * B operand: lane (i, kq) owns patch i of its wave's 16-patch group (8 patch columns x 2 patch rows = 16 x 4 output
+    //     pixels) and channels 4kq..4kq+3: 16 ds_read_b128 of the staged halo (the 4x4 input window of the patch), the input
+    //     transform V = B^T d B on float4 registers (rows, then columns: 32 packed-pair adds each), and V[xi] feeds 4 MFMAs
+    //     (k-step j contracts channel 4kq+j) -- the same lane map as the direct kernel, with xi in place of the tap;
+    //   * A operand: the transform-domain weights U[xi] = G g G^T, packed per (cout block, cin block, xi) in fragment order by
+    //     pack_weights_kernel; resident in registers, the next item's fetched xi-row by xi-row behind the MFMAs that used it;
+    //   * the output transform A^T M A is linear, so it is applied per channel block (item) to the xi-row's four
+    //     accumulators as soon as they complete and summed into the patch's 2x2 outputs Y: only 4 + 4 accumulators
+    //     (+ the software-pipelined second set) are live instead of 16 per patch.
+    // Waves split the tile as in the direct kernel (cout blocks for NB >= 2, 4-row groups otherwise); a wave that shares a
+    // patch group with another cout block's wave repeats the input transform (VALU in exchange for no LDS round trip of V).
+    constexpr int NGRP = NG / 4;                       // 16-patch groups (4 tile rows each) per wave
+    static_assert(CBW == 1, "one cout block per wave");
+    const int pxp = lane & 7, pyl = (lane >> 3) & 1;
+    const int lbase = kq * WPLANE + (g0 + 2 * pyl) * WPITCH + pxp;
+    const __amdgpu_buffer_rsrc_t rww = make_rsrc(a.wpack, (unsigned)(NB * 16) * (unsigned)(NQ * 16) * 64u);
+    float4 wq[16];
+    auto wsoff = [&](int q_, int xi) { return (unsigned)(((nb0 * NQ + q_) * 16 + xi)) * 1024u; };
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) wq[xi] = bload4(rww, (unsigned)lane * 16u, wsoff(0, xi));
+
+    f32x4 Y[NGRP][2][2];
+#pragma unroll
+    for (int g = 0; g < NGRP; ++g)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) Y[g][o >> 1][o & 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto add4 = [](float4 u, float4 v) { return make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w); };
+    auto sub4 = [](float4 u, float4 v) { return make_float4(u.x - v.x, u.y - v.y, u.z - v.z, u.w - v.w); };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int buf = 0, q = 0;
+
+    while (true) {
+      __syncthreads();   // lds[buf] holds this item; the producers may now refill the other buffer
+      const bool last_q = q + 1 == NQ;
+      const int t_next = t + t_step;
+      const bool more = !last_q || t_next < t_hi;
+      const int qn = last_q ? 0 : q + 1;
+
+      // fused BatchNorm-backward sums of the previous layer (NB == 1 dgrad): its y at this lane's 2x2 output pixels,
+      // requested before the MFMA work of the tile's last channel block (see the direct kernel)
+      float4 yq[NB == 1 ? 4 : 1];
+      float4 bsc = make_float4(0.f, 0.f, 0.f, 0.f), bsh = bsc;
+      if (NB == 1 && bn_stats && last_q) {
+        int cb_, txi_, tyi_;
+        tile_pos(t, cb_, txi_, tyi_);
+        const int y0_ = tyi_ * 16 + g0 + 2 * pyl, x0_ = txi_ * 16 + 2 * pxp;
+        bsc = ld4(a.bn_scale + 4 * kq); bsh = ld4(a.bn_shift + 4 * kq);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const int yy_ = y0_ + (o >> 1), xx_ = x0_ + (o & 1);
+          yq[o] = bload4(rby, (yy_ < H && xx_ < W) ? (unsigned)((cb_ * H + yy_) * W + xx_) * 64u + (unsigned)kq * 16u : OOB, 0u);
+        }
+      }
+
+      const float4* L = lds[buf];
+      __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+      for (int g = 0; g < NGRP; ++g) {
+        // ---- the patch's 4x4 input window -> V = B^T d B (in place)
+        float4 d[4][4];
+        const float4* Lg = L + lbase + g * 4 * WPITCH;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          d[r][0] = Lg[r * WPITCH]; d[r][1] = Lg[r * WPITCH + WHALF]; d[r][2] = Lg[r * WPITCH + 1]; d[r][3] = Lg[r * WPITCH + WHALF + 1];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {     // rows: [d0 - d2, d1 + d2, d2 - d1, d1 - d3]
+          const float4 r0 = sub4(d[0][c], d[2][c]), r1 = add4(d[1][c], d[2][c]), r2 = sub4(d[2][c], d[1][c]), r3 = sub4(d[1][c], d[3][c]);
+          d[0][c] = r0; d[1][c] = r1; d[2][c] = r2; d[3][c] = r3;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {     // columns, same pattern
+          const float4 c0 = sub4(d[r][0], d[r][2]), c1 = add4(d[r][1], d[r][2]), c2 = sub4(d[r][2], d[r][1]), c3 = sub4(d[r][1], d[r][3]);
+          d[r][0] = c0; d[r][1] = c1; d[r][2] = c2; d[r][3] = c3;
+        }
+        // ---- per xi-row a: M[b] = U[a][b] * V[a][b] over the 16 channels (4 MFMAs each, 4 independent chains), then
+        // t = M A (2 columns) and Y += A^T rows: Y[0] += t for a = 0, 1, 2;  Y[1] += t, -t, -t for a = 1, 2, 3
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar) {
+          f32x4 M[4];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) M[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[4 * ar + b].x, d[ar][b].x, zero4, 0, 0, 0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) M[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[4 * ar + b].y, d[ar][b].y, M[b], 0, 0, 0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) M[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[4 * ar + b].z, d[ar][b].z, M[b], 0, 0, 0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) M[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[4 * ar + b].w, d[ar][b].w, M[b], 0, 0, 0);
+          if (g == NGRP - 1) {
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch behind this xi-row's MFMAs (see the direct kernel)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) wq[4 * ar + b] = bload4(rww, (unsigned)lane * 16u, wsoff(qn, 4 * ar + b));
+          }
+          const f32x4 t0 = M[0] + M[1] + M[2], t1 = M[1] - M[2] - M[3];
+          if (ar <= 2) { Y[g][0][0] += t0; Y[g][0][1] += t1; }
+          if (ar == 1) { Y[g][1][0] += t0; Y[g][1][1] += t1; }
+          if (ar >= 2) { Y[g][1][0] -= t0; Y[g][1][1] -= t1; }
+        }
+      }
+      __builtin_amdgcn_s_setprio(2);
+      buf ^= 1;
+      if (!last_q) { ++q; continue; }
+
+      // ---- tile epilogue: the lane's 2x2 output pixels x 4 channels per group
+      int cb, txi, tyi;
+      tile_pos(t, cb, txi, tyi);
+      const bool do_stats = a.stat_partials != nullptr && !bn_stats;
+      const bool d0 = nb0 < a.dst_split;
+      const int dC = d0 ? a.dst[0].C : a.dst[1].C;
+      const __amdgpu_buffer_rsrc_t rd = d0 ? rd0 : rd1;
+      const unsigned chb = (unsigned)((d0 ? a.dst[0].coff + 16 * nb0 : a.dst[1].coff + 16 * (nb0 - a.dst_split)) + 4 * kq) * 4u;
+#pragma unroll
+      for (int g = 0; g < NGRP; ++g) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const int oy = o >> 1, ox = o & 1;
+          const int yy = tyi * 16 + g0 + 4 * g + 2 * pyl + oy, xx = txi * 16 + 2 * pxp + ox;
+          const bool ok = yy < H && xx < W;
+          f32x4 v = Y[g][oy][ox];
+          Y[g][oy][ox] = zero4;
+          const unsigned pixo = (unsigned)((cb * H + yy) * W + xx);
+          if (a.addend != nullptr) {
+            const float4 ad = bload4(rad, ok ? pixo * (unsigned)a.addC * 4u + (unsigned)(16 * nb0 + 4 * kq) * 4u : OOB, 0u);
+            v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+          }
+          bstore4(rd, ok ? pixo * (unsigned)dC * 4u + chb : OOB, 0u, make_float4(v[0], v[1], v[2], v[3]));
+          if (NB == 1 && bn_stats) {
+            const float yy4[4] = {yq[o].x, yq[o].y, yq[o].z, yq[o].w};
+            const float scv[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, shv[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float dz = (ok && fmaf(yy4[r], scv[r], shv[r]) > 0.f) ? v[r] : 0.f;
+              s1[0][r] += dz; s2[0][r] = fmaf(dz, yy4[r], s2[0][r]);
+            }
+          } else if (do_stats) {
+            if (!ok) v = zero4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[0][r] += v[r]; s2[0][r] = fmaf(v[r], v[r], s2[0][r]); }
+          }
+        }
+      }
+      if (!more) break;
+      t = t_next; q = 0;
+    }
+  } else {
   load_weights(0);   // NQ == 1 (single 16-channel block): the weights stay in registers for every tile
   int buf = 0, q = 0;
 
@@ -523,6 +682,8 @@ __global__ __launch_bounds__(512, (NB <= 2 && MODE != 2 ? 4 : 2)) void conv3x3_m
     t = t_next; q = 0;
   }
 
+  }   // direct (non-Winograd) consumer
+
   // ---- per-workgroup BatchNorm partials (sum, sumsq) over all tiles this workgroup produced ----
   if (a.stat_partials != nullptr) {
 #pragma unroll
@@ -600,6 +761,42 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
         const __bf16 lo = (__bf16)(r - (float)mid);
         h[k * n + e] = hi; h[2 * n + k * n + e] = mid; h[4 * n + k * n + e] = lo;
       }
+    }
+  }
+}
+
+// Winograd-domain weights U = G g G^T (4x4 per (cout, cin) pair; G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]) in
+// fragment order, for the forward (g = W[co][ci]) and for the input gradient (g = W[co][ci] transposed and flipped):
+//   ww[nb][q][xi][lane][j], xi = 4a + b, same (lane, j) -> (row, k) map as the tap packs above; 16*cin*cout floats each.
+__global__ void pack_wino_kernel(const float* __restrict__ params, float* __restrict__ wwf, float* __restrict__ wwd,
+                                 const PackTable tb) {
+  const int l = blockIdx.y;
+  const int cin = tb.cin[l], cout = tb.cout[l];
+  const int n = 16 * cin * cout;
+  const float* W = params + tb.w_off[l];
+  const size_t off = (size_t)tb.p_off[l] / 9 * 16;
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int j = e & 3, lane = (e >> 2) & 63;
+    const int rest = e >> 8;
+    const int xi = rest & 15, r2 = rest >> 4;
+    const int xa = xi >> 2, xb = xi & 3;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int NQ = (k == 0 ? cin : cout) / 16;
+      const int q = r2 % NQ, nb = r2 / NQ;
+      const int co = k == 0 ? 16 * nb + (lane & 15) : 16 * q + 4 * (lane >> 4) + j;
+      const int ci = k == 0 ? 16 * q + 4 * (lane >> 4) + j : 16 * nb + (lane & 15);
+      const float* g = W + (size_t)(co * cin + ci) * 9;
+      float u = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        float row = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) row += g[k == 0 ? 3 * r + c : 8 - (3 * r + c)] * G[xb][c];
+        u += G[xa][r] * row;
+      }
+      (k == 0 ? wwf : wwd)[off + e] = u;
     }
   }
 }
@@ -769,9 +966,14 @@ __global__ __launch_bounds__(256, 8) void dgrad_border_kernel(const float* __res
 
 // Number of persistent workgroups (== rows of stat_partials written) for a B x H x W conv with cout outputs:
 // at most 256 CUs x the residency the kernel variant reaches, and an even split of the tiles.
-int conv3x3_grid_blocks(int B, int H, int W, int cout) {
+bool conv3x3_use_wino(const ConvArgs& a, int cout) {
+  static const int off = getenv("SIFSR_NO_WINO") ? atoi(getenv("SIFSR_NO_WINO")) : 0;   // 1: direct kernels everywhere (A/B, debugging)
+  return !off && a.wpack_wino != nullptr && a.bf16 == 0 && cout <= 64 && a.H % 2 == 0 && a.W % 2 == 0;
+}
+
+int conv3x3_grid_blocks(int B, int H, int W, int cout, int wino) {
   const int ntiles = B * ((H + 15) / 16) * ((W + 15) / 16);
-  const int per_cu = cout >= 64 ? 1 : 2;   // residency of the kernel variants (VGPR-limited)
+  const int per_cu = (wino || cout >= 64) ? 1 : 2;   // residency of the kernel variants (VGPR-limited)
   static const int dbg_grid = getenv("SIFSR_DBG_CONV_GRID") ? atoi(getenv("SIFSR_DBG_CONV_GRID")) : 0;   // tuning knob
   const int gmax = dbg_grid > 0 ? dbg_grid : 256 * per_cu;
   if (ntiles <= gmax) return ntiles;
@@ -801,7 +1003,30 @@ int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s
   const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
   const bool dyf = a.bw_y != nullptr;
   if (dyf && (!zero_pad || !a.bw_coef || a.src[1].ptr || a.src[0].scale || a.src[0].coff)) return SIFSR_ERR_ARG;
-#define SIFSR_CONV_LAUNCH(NBV, ZP, MD, DY) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, ZP, MD, DY>), grid, block, 0, s, a, ntiles, lgx, lgy)
+  if (conv3x3_use_wino(a, cout)) {
+    // Winograd F(2x2,3x3) consumers (fp32, <= 64 output channels, even image sizes): a.wpack_wino replaces a.wpack
+    ConvArgs w = a;
+    w.wpack = a.wpack_wino;
+    const dim3 wgrid(conv3x3_grid_blocks(a.B, a.H, a.W, cout, 1));
+#define SIFSR_WINO_LAUNCH(NBV, ZP, DY) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, ZP, 0, DY, true>), wgrid, block, 0, s, w, ntiles, lgx, lgy)
+#define SIFSR_WINO_CASE(NBV)                                                                              \
+  case NBV:                                                                                               \
+    if (dyf) SIFSR_WINO_LAUNCH(NBV, true, true);                                                          \
+    else if (zero_pad) SIFSR_WINO_LAUNCH(NBV, true, false);                                               \
+    else SIFSR_WINO_LAUNCH(NBV, false, false);                                                            \
+    break;
+    switch (nb) {
+      SIFSR_WINO_CASE(1)
+      SIFSR_WINO_CASE(2)
+      SIFSR_WINO_CASE(4)
+      default: return SIFSR_ERR_SHAPE;
+    }
+#undef SIFSR_WINO_CASE
+#undef SIFSR_WINO_LAUNCH
+    SIFSR_LAUNCH_CHECK();
+    return SIFSR_OK;
+  }
+#define SIFSR_CONV_LAUNCH(NBV, ZP, MD, DY) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, ZP, MD, DY, false>), grid, block, 0, s, a, ntiles, lgx, lgy)
 #define SIFSR_CONV_MODE(NBV, MD)                                                                          \
     if (dyf) SIFSR_CONV_LAUNCH(NBV, true, MD, true);                                                      \
     else if (zero_pad) SIFSR_CONV_LAUNCH(NBV, true, MD, false);                                           \
@@ -826,7 +1051,7 @@ int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s
   return SIFSR_OK;
 }
 
-int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStream_t s) {
+int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStream_t s, float* wwf, float* wwd) {
   const NetTable& nt = sifsr_net();
   PackTable tb;
   int maxn = 0;
@@ -841,16 +1066,26 @@ int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStre
   const dim3 grid((maxn + 255) / 256 > 64 ? 64 : (maxn + 255) / 256, 16);
   hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, s, params, wfwd, wdgrad, tb);
   SIFSR_LAUNCH_CHECK();
+  if (wwf != nullptr && wwd != nullptr) {
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(grid.x * 2, 16), dim3(256), 0, s, params, wwf, wwd, tb);
+    SIFSR_LAUNCH_CHECK();
+  }
   return SIFSR_OK;
 }
 
-int launch_pack_weights_one(const float* w, int cin, int cout, float* wfwd, float* wdg, hipStream_t s) {
+int launch_pack_weights_one(const float* w, int cin, int cout, float* wfwd, float* wdg, hipStream_t s, float* wwf, float* wwd) {
   PackTable tb;
   tb.w_off[0] = 0; tb.cin[0] = cin; tb.cout[0] = cout; tb.p_off[0] = 0;
   const int n = 9 * cin * cout;
   const dim3 grid((n + 255) / 256 > 64 ? 64 : (n + 255) / 256, 1);
-  hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, s, w, wfwd, wdg, tb);
-  SIFSR_LAUNCH_CHECK();
+  if (wfwd != nullptr && wdg != nullptr) {
+    hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, s, w, wfwd, wdg, tb);
+    SIFSR_LAUNCH_CHECK();
+  }
+  if (wwf != nullptr && wwd != nullptr) {
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(grid.x * 2, 1), dim3(256), 0, s, w, wwf, wwd, tb);
+    SIFSR_LAUNCH_CHECK();
+  }
   return SIFSR_OK;
 }
 

@@ -10,6 +10,7 @@ struct WsLayout {
   size_t npix[4];                         // B*H*W at the four resolution levels
   size_t mean, invstd, scale, shift;      // per-channel vectors, all 17 BN layers back to back
   size_t wfwd, wdg;                       // fragment-ordered conv weights (forward / dgrad)
+  size_t wwf, wwd;                        // the same in the Winograd F(2x2,3x3) domain (16 instead of 9 values per weight pair)
   size_t y[SIFSR_NUM_BN_LAYERS];          // raw conv outputs (pre-BN), NHWC
   size_t P[3], R[3], U[3];                // pooled inputs, residual sums, upsampled decoder inputs
   size_t partials;                        // BN statistic partials (scratch)

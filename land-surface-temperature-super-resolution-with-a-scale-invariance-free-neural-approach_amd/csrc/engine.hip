@@ -80,6 +80,7 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
   w.mean = take(nt.total_channels); w.invstd = take(nt.total_channels);
   w.scale = take(nt.total_channels); w.shift = take(nt.total_channels);
   w.wfwd = take(nt.total_wpack); w.wdg = take(4 * (size_t)nt.total_wpack);
+  w.wwf = take((size_t)nt.total_wpack / 9 * 16); w.wwd = take((size_t)nt.total_wpack / 9 * 16);   // Winograd-domain packs
   for (int l = 0; l < SIFSR_NUM_BN_LAYERS; ++l) w.y[l] = take(nt.L[l].cout * N[nt.L[l].level]);
   static const int pc[3] = {16, 32, 64};
   for (int k = 0; k < 3; ++k) {
@@ -266,6 +267,7 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
     const size_t n = (size_t)9 * L.cin * L.cout;   // bf16 packs live behind the layer's fp32 dgrad pack
     a.wpack = a.bf16 ? c.f(c.lay.wdg) + 4 * (size_t)L.wpack_off + n : c.f(c.lay.wfwd) + L.wpack_off;
   }
+  a.wpack_wino = c.f(c.lay.wwf) + (size_t)L.wpack_off / 9 * 16;
   a.addend = nullptr; a.addC = 0;
   a.stat_partials = training ? c.f(c.lay.partials) : nullptr;
   a.dst_split = L.cout / 16;
@@ -276,7 +278,7 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
     SIFSR_TRY(launch_conv3x3_mfma(a, L.cout, 0, c.s));
   }
   if (training) {
-    const int nblk = conv3x3_grid_blocks(c.B, a.H, a.W, L.cout);
+    const int nblk = conv3x3_grid_blocks(c.B, a.H, a.W, L.cout, conv3x3_use_wino(a, L.cout));
     SIFSR_TRY(launch_bn_finalize(c.f(c.lay.partials), nblk, L.cout, (double)c.B * a.H * a.W, c.params + L.gamma_off,
                                  c.params + L.beta_off, running + L.run_off, running + L.run_off + L.cout, momentum, eps,
                                  c.f(c.lay.mean) + L.ch_off, c.f(c.lay.invstd) + L.ch_off,
@@ -374,6 +376,7 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
     const size_t n = (size_t)9 * L.cin * L.cout;
     a.wpack = a.bf16 ? wdg_f32 + n + n / 2 : wdg_f32;   // [fp32 dgrad | fwd hi (n/2 floats) | dgrad hi | mid, lo packs]
   }
+  a.wpack_wino = c.f(c.lay.wwd) + (size_t)L.wpack_off / 9 * 16;
   a.addend = addend; a.addC = L.cin;
   a.stat_partials = nullptr;
   a.dst_split = split_ch / 16;
@@ -382,7 +385,7 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
   if (fuse) {
     a.stat_partials = c.f(c.lay.partials);
     a.bn_y = c.f(c.lay.y[bn_layer]); a.bn_scale = c.scale(bn_layer); a.bn_shift = c.shift(bn_layer);
-    if (stat_rows) *stat_rows = conv3x3_grid_blocks(c.B, a.H, a.W, L.cin);
+    if (stat_rows) *stat_rows = conv3x3_grid_blocks(c.B, a.H, a.W, L.cin, conv3x3_use_wino(a, L.cin));
   }
   {
     ProfScope ps(l, 2, c.s);
@@ -414,7 +417,7 @@ int sifsr_engine_forward(const float* x, float* sr, const float* params, float* 
   const NetTable& nt = c.nt;
   const WsLayout& w = c.lay;
 
-  SIFSR_TRY(launch_pack_weights(params, c.f(w.wfwd), c.f(w.wdg), s));
+  SIFSR_TRY(launch_pack_weights(params, c.f(w.wfwd), c.f(w.wdg), s, c.f(w.wwf), c.f(w.wwd)));
   if (training) {
     if (nbt) SIFSR_TRY(launch_nbt_increment(nbt, SIFSR_NUM_BN_LAYERS, s));
   } else {

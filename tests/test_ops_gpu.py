@@ -122,10 +122,34 @@ def test_conv3x3_fwd_dgrad_wgrad(L, case):
     torch.cuda.synchronize()
     g = nchw(g0.cpu()) if not C1 else torch.cat([nchw(g0.cpu()), nchw(g1.cpu())], 1)
     assert rel_err(g, ga_ref) < TOL
+    add = rnd(rs, B, cin, H, W)
     if not C1:   # residual addend variant
-        add = rnd(rs, B, cin, H, W)
         g2 = torch.empty(B, H, W, cin, device="cuda")
         L.call("sifsr_conv3x3_dgrad", ddy, cout, wd, dw_, cin, g2, cin, None, 0, dev(nhwc(add)), B, H, W, S())
+        torch.cuda.synchronize()
+        assert rel_err(nchw(g2.cpu()), ga_ref + add) < TOL
+
+    # ---- the same two passes in the Winograd F(2x2,3x3) domain (what the model runs; odd sizes fall back to the taps)
+    wwf = torch.empty(16 * cin * cout, device="cuda"); wwd = torch.empty(16 * cin * cout, device="cuda")
+    L.call("sifsr_pack_conv_weights_wino", dw_, cin, cout, wwf, wwd, S())
+    yw = torch.full((B, H, W, cout), float("nan"), device="cuda")
+    nblk_w = L.call("sifsr_conv3x3_stat_blocks_wino", B, H, W, cout)
+    part_w = torch.empty(nblk_w, cout, 2, device="cuda")
+    L.call("sifsr_conv3x3_fwd_wino", d0, C0, dsc0, dsh0, d1, C1, dsc1, dsh1, wf, wwf, yw, cout, part_w, B, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(nchw(yw.cpu()), y_ref) < TOL
+    ps = part_w.cpu().double().sum(0)
+    assert torch.allclose(ps[:, 0], yr.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(ps[:, 1], (yr * yr).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    g0 = torch.full((B, H, W, C0), float("nan"), device="cuda")
+    g1 = torch.full((B, H, W, C1), float("nan"), device="cuda") if C1 else None
+    L.call("sifsr_conv3x3_dgrad_wino", ddy, cout, wd, wwd, cin, g0, C0, g1, C1, None, B, H, W, S())
+    torch.cuda.synchronize()
+    g = nchw(g0.cpu()) if not C1 else torch.cat([nchw(g0.cpu()), nchw(g1.cpu())], 1)
+    assert rel_err(g, ga_ref) < TOL
+    if not C1:
+        g2 = torch.full((B, H, W, cin), float("nan"), device="cuda")
+        L.call("sifsr_conv3x3_dgrad_wino", ddy, cout, wd, wwd, cin, g2, cin, None, 0, dev(nhwc(add)), B, H, W, S())
         torch.cuda.synchronize()
         assert rel_err(nchw(g2.cpu()), ga_ref + add) < TOL
 
@@ -526,16 +550,19 @@ def test_bn_relu_backward_fused_into_dgrad_and_wgrad(L, case):
     assert rel_err(dgam.cpu(), dgam_ref) < TOL and rel_err(dbet.cpu(), dbet_ref) < TOL
     if pool:
         assert rel_err(nchw(dg.cpu()), g_eff) < 1e-6       # completed in place
-    border = torch.full((B, H, W, cout), float("nan"), device="cuda")
-    gin = torch.full((B, H, W, cin), float("nan"), device="cuda")
-    L.call("sifsr_conv3x3_dgrad_fused", dg, y, coef_f, cout, wd, cin, gin, cin, None, 0, None, border, B, H, W, S())
-    torch.cuda.synchronize()
-    assert rel_err(nchw(gin.cpu()), ga_ref) < TOL
-    assert rel_err(gin, gin_u) < 2e-5                      # the fp32 on-load form against the float64 stored form
-    bc = nchw(border.cpu())
+    wwf = torch.empty(16 * cin * cout, device="cuda"); wwd = torch.empty(16 * cin * cout, device="cuda")
+    L.call("sifsr_pack_conv_weights_wino", dev(w), cin, cout, wwf, wwd, S())
     edge = torch.zeros(H, W, dtype=torch.bool); edge[0] = edge[-1] = True; edge[:, 0] = edge[:, -1] = True
-    assert torch.isnan(bc[:, :, ~edge]).all()              # only border pixels are written ...
-    assert rel_err(bc[:, :, edge], dy64[:, :, edge]) < TOL  # ... with dL/dy
+    for wino in (None, wwd):                               # tap-domain and Winograd-domain contraction
+        border = torch.full((B, H, W, cout), float("nan"), device="cuda")
+        gin = torch.full((B, H, W, cin), float("nan"), device="cuda")
+        L.call("sifsr_conv3x3_dgrad_fused", dg, y, coef_f, cout, wd, wino, cin, gin, cin, None, 0, None, border, B, H, W, S())
+        torch.cuda.synchronize()
+        assert rel_err(nchw(gin.cpu()), ga_ref) < TOL
+        assert rel_err(gin, gin_u) < 2e-5                      # the fp32 on-load form against the float64 stored form
+        bc = nchw(border.cpu())
+        assert torch.isnan(bc[:, :, ~edge]).all()              # only border pixels are written ...
+        assert rel_err(bc[:, :, edge], dy64[:, :, edge]) < TOL  # ... with dL/dy
     for nbk in (1, 7, 64):
         scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_scratch_floats", cin, cout, nbk), device="cuda")
         dwo = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
