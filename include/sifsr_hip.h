@@ -95,7 +95,7 @@ SIFSR_API int sifsr_conv3x3_dgrad_fused(const float* g, const float* y, const fl
  * tap packs are still passed (shapes the Winograd kernel does not take fall back to them; the border fold uses wdgrad).
  * stat_partials rows: sifsr_conv3x3_stat_blocks_wino(). */
 SIFSR_API int sifsr_pack_conv_weights_wino(const float* w_oihw, int cin, int cout, float* wwf, float* wwd, void* stream);
-SIFSR_API int sifsr_conv3x3_stat_blocks_wino(int B, int H, int W, int cout);
+SIFSR_API int sifsr_conv3x3_stat_blocks_wino(int B, int H, int W, int cin, int cout);
 SIFSR_API int sifsr_conv3x3_fwd_wino(const float* src0, int C0, const float* scale0, const float* shift0,
                                      const float* src1, int C1, const float* scale1, const float* shift1,
                                      const float* wfwd, const float* wwf, float* y, int cout, float* stat_partials,

@@ -79,9 +79,10 @@ int sifsr_pack_conv_weights_wino(const float* w_oihw, int cin, int cout, float* 
   return launch_pack_weights_one(w_oihw, cin, cout, nullptr, nullptr, S(stream), wwf, wwd);
 }
 int sifsr_conv3x3_stat_blocks(int B, int H, int W, int cout) { return conv3x3_grid_blocks(B, H, W, cout); }
-int sifsr_conv3x3_stat_blocks_wino(int B, int H, int W, int cout) {
+int sifsr_conv3x3_stat_blocks_wino(int B, int H, int W, int cin, int cout) {
   ConvArgs a; a.B = B; a.H = H; a.W = W; a.wpack_wino = reinterpret_cast<const float*>(1);   // shape decision only
-  return conv3x3_grid_blocks(B, H, W, cout, conv3x3_use_wino(a, cout));
+  a.NQ = cin / 16;
+  return conv3x3_grid_blocks(B, H, W, cout, conv3x3_wino_kind(a, cout, 0));
 }
 
 int sifsr_conv3x3_fwd(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,

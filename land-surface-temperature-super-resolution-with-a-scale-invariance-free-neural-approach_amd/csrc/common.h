@@ -46,6 +46,21 @@ static __device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh
   return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 
+// a - b on a register pair as ONE instruction: v_pk_add_f32 with the negate modifiers on b.  (hipcc emits v_pk_add_f32 for
+// the sum of two float2 values but scalarises their difference into two v_sub_f32 -- twice the issue slots on a SIMD whose
+// matrix pipe waits for every vector instruction.)  Exact, like the subtraction it replaces.
+static __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+static __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {   // same reason: not every float2 sum comes out packed
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // BatchNorm + ReLU BACKWARD applied while a consumer stages its operand (the input-gradient and weight-gradient
 // convolutions of layer l read g_l = dL/d relu(bn(y_l)) and y_l instead of a stored dL/dy_l):
 //   z  = fma(y, sc, sh)                      the forward's pre-activation, bit for bit (same fma) -> same ReLU mask

@@ -53,7 +53,8 @@ struct ConvArgs {
 // of the transposed conv used by dgrad; the replicate-border fold is dgrad_border_fix).
 int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s);
 bool conv3x3_use_wino(const ConvArgs& a, int cout);
-// workgroups launched == stat_partials rows written; wino = conv3x3_use_wino() of the same call
+int conv3x3_wino_kind(const ConvArgs& a, int cout, int zero_pad);   // 0 tap-domain, 1 / 2 Winograd variants (residency differs)
+// workgroups launched == stat_partials rows written; wino = conv3x3_wino_kind() of the same call
 int conv3x3_grid_blocks(int B, int H, int W, int cout, int wino = 0);
 
 struct WgradArgs {

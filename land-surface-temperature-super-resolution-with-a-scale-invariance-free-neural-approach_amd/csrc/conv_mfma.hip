@@ -30,7 +30,9 @@ constexpr int PLANE = 336;    // 18*18 = 324 pixels, padded to a multiple of 16 
 // in [WHALF, WHALF + 9), so that the 4 consecutive pixels of a patch row are slots {x/2, WHALF + x/2, x/2 + 1, WHALF + x/2 + 1}
 // and the 16 lanes of a read (8 patches of one patch row | 8 of the next, 2 halo rows = 2 * WPITCH slots = 640 B = 128 (mod
 // 256) further) cover all 64 banks exactly once.
-constexpr int WPITCH = 20, WHALF = 10, WPLANE = PW * WPITCH;   // 360 slots per channel quad
+// The plane (channel quad) stride is = 4 or 12 (mod 16) slots, so that the four quads of a pixel -- written by four neighbouring
+// producer lanes -- start 64 B apart in the 256-byte bank row and a 16-lane ds_write_b128 (4 pixels x 4 quads) is conflict-free.
+constexpr int WPITCH = 20, WHALF = 10, WPLANE = 364;   // >= 18 * WPITCH = 360 slots per channel quad; 364 = 12 (mod 16)
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -110,8 +112,12 @@ static __device__ __forceinline__ uint2 bload2(__amdgpu_buffer_rsrc_t r, unsigne
 // (bn_bwd4) -- the BatchNorm-backward elementwise pass and its tensor round trip do not exist (ConvArgs::bw_*).
 // WINO (fp32 only): the consumers contract in the Winograd F(2x2, 3x3) domain -- per 2x2 output patch and channel
 // 16 products instead of 36 -- see the consumer branch.  One workgroup per CU (the transforms want registers).
+// WINO forward with NB == 1 (16 output channels: the layers with the least matrix work per byte): the transform-domain weights of
+// the layer (<= 2 channel blocks, 16 KB each) live in LDS instead of 64 registers per lane and the output transform is not
+// software-pipelined, which brings the kernel under 128 registers -> TWO workgroups per CU, i.e. a second consumer wave
+// per SIMD to issue while the first one waits (measured at one workgroup per CU: matrix pipe busy 32 %, SIMD idle half the time).
 template <int NB, bool ZERO_PAD, int MODE, bool DYF, bool WINO>
-__global__ __launch_bounds__(512, (WINO ? 2 : (NB <= 2 && MODE != 2 ? 4 : 2))) void conv3x3_mfma_kernel(const ConvArgs a, const int ntiles, const int lgx,
+__global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <= 2 && MODE != 2 ? 4 : 2))) void conv3x3_mfma_kernel(const ConvArgs a, const int ntiles, const int lgx,
                                                            const int lgy) {
   static_assert(!DYF || ZERO_PAD, "the fused BatchNorm backward belongs to the input-gradient pass");
   static_assert(!WINO || (MODE == 0 && NB <= 4), "the Winograd consumer is fp32, up to 64 output channels");
@@ -125,6 +131,9 @@ __global__ __launch_bounds__(512, (WINO ? 2 : (NB <= 2 && MODE != 2 ? 4 : 2))) v
 
   __shared__ float4 lds[2][WINO ? 4 * WPLANE : (X3 ? 6 : 4) * PLANE];   // X3: three planes of 8 B per (pixel, channel quad)
   __shared__ float red[4][CBW][16][2];
+  // (forward only: the input-gradient variants carry the fused BatchNorm work of two layers and measured slower this way)
+  constexpr bool WLDS = WINO && NB == 1 && !ZERO_PAD;
+  __shared__ float4 wlds[WLDS ? 2 * 16 * 64 : 1];   // WLDS: [channel block q < 2][xi][lane] fragment-ordered weights
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -152,6 +161,11 @@ __global__ __launch_bounds__(512, (WINO ? 2 : (NB <= 2 && MODE != 2 ? 4 : 2))) v
     if (lgx >= 0) { tyi = (tt >> lgx) & (tiles_y - 1); tb = tt >> (lgx + lgy); txi = (tt + tyi + tb) & (tiles_x - 1); }   // column rotated per row: no workgroup is pinned to a border column
     else { txi = tt % tiles_x; const int r = tt / tiles_x; tyi = r % tiles_y; tb = r / tiles_y; }
   };
+
+  if (WLDS) {   // (a.NQ <= 2, checked by the launcher)
+    for (int i = tid; i < a.NQ * 16 * 64; i += 512) wlds[i] = ld4(a.wpack + 4 * (size_t)i);
+    __syncthreads();
+  }
 
   if (producer) {
     // =========================================== PRODUCER ===========================================
@@ -201,14 +215,23 @@ __global__ __launch_bounds__(512, (WINO ? 2 : (NB <= 2 && MODE != 2 ? 4 : 2))) v
     // One item in flight: the loads of item j+1 are issued right after item j went to LDS and land while the
     // consumers work on item j.  (Two register sets / two items in flight measured 4 % slower: the consumers,
     // not the load latency, are the critical path.)
-    float4 stgA[6], scA, shA;
-    float4 styA[DYF ? 6 : 1], k1A = make_float4(0.f, 0.f, 0.f, 0.f), k0A = k1A;   // DYF: y of the same slots, two more coefficient quads
-    bool rawA = true;
+    // WINO (one workgroup per CU, items half as long): DEPTH register sets = DEPTH items in flight, so that the loads of
+    // item j + DEPTH are issued when item j goes to LDS and have DEPTH item times to land (HBM latency under load is 2-3 us,
+    // a Winograd item ~2 us).  The two-workgroups-per-CU variants (direct; Winograd with 16 output channels) keep one set:
+    // the workgroups cover each other and the registers are needed elsewhere.
+    constexpr int DEPTH = (WINO && !WLDS) ? (DYF ? 2 : 3) : 1;
+    float4 stgS[DEPTH][6], scS[DEPTH], shS[DEPTH];
+    float4 styS[DYF ? DEPTH : 1][DYF ? 6 : 1], k1S[DEPTH], k0S[DEPTH];   // DYF: y of the same slots, two more coefficient quads
+    bool rawS[DEPTH];
     int it_t = t, it_q = 0;       // next item to fetch; past the end the last item is fetched again (never used)
-    int tA = t, qA = 0;           // DYF: (tile, channel block) of the item held in stgA (for the masks of write_stage)
-    auto issue_loads = [&](float4 (&stg)[6], float4& psc, float4& psh, bool& praw) {
+    int tS[DEPTH], qS[DEPTH];     // DYF: (tile, channel block) of the item held in set k (for the masks of write_stage)
+    auto issue_loads = [&](const int k) {
+      float4 (&stg)[6] = stgS[k];
+      float4 (&styA)[DYF ? 6 : 1] = styS[DYF ? k : 0];
+      float4 &psc = scS[k], &psh = shS[k], &k1A = k1S[k], &k0A = k0S[k];
+      bool& praw = rawS[k];
       const int q = it_q;
-      if (DYF) { tA = it_t; qA = it_q; }
+      tS[k] = it_t; qS[k] = it_q;
       const bool first = q < a.src[0].nq;
       const int C = first ? a.src[0].C : a.src[1].C;
       const int lgc = 31 - __builtin_clz((unsigned)C) + 2;                       // log2(C * 4 bytes)
@@ -235,7 +258,12 @@ __global__ __launch_bounds__(512, (WINO ? 2 : (NB <= 2 && MODE != 2 ? 4 : 2))) v
       if (it_q + 1 < NQ) ++it_q;
       else if (it_t + t_step < t_hi) { it_t += t_step; it_q = 0; set_tile(it_t); }
     };
-    auto write_stage = [&](float4* Lb, const float4 (&stg)[6], const float4 psc, const float4 psh, const bool praw) {
+    auto write_stage = [&](float4* Lb, const int k) {
+      const float4 (&stg)[6] = stgS[k];
+      const float4 (&styA)[DYF ? 6 : 1] = styS[DYF ? k : 0];
+      const float4 psc = scS[k], psh = shS[k], k1A = k1S[k], k0A = k0S[k];
+      const bool praw = rawS[k];
+      const int tA = tS[k], qA = qS[k];
       // DYF: tile of THIS item (the tile state above already belongs to the next one).  Halo pixels outside the image
       // are zero padding of dL/dy (bn_bwd4 of the zeros they loaded is not 0), and the image-border pixels of the tile's
       // own 16x16 core go to bw_border for the border-fold kernel.  Interior tiles need neither.
@@ -278,11 +306,17 @@ __global__ __launch_bounds__(512, (WINO ? 2 : (NB <= 2 && MODE != 2 ? 4 : 2))) v
 
     const int n_items = ((t_hi - t + t_step - 1) / t_step) * NQ;
     set_tile(t);
-    issue_loads(stgA, scA, shA, rawA);
-    for (int j = 0; j < n_items; ++j) {
-      write_stage(lds[j & 1], stgA, scA, shA, rawA);
-      issue_loads(stgA, scA, shA, rawA);   // next item (past the end: the last one again, never used)
-      __syncthreads();                      // item j staged; the consumers have drained the other buffer
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) issue_loads(k);
+    for (int j = 0; j < n_items; j += DEPTH) {
+#pragma unroll
+      for (int k = 0; k < DEPTH; ++k) {
+        if (j + k < n_items) {                // uniform over the workgroup's producers: one barrier per item, as the consumers
+          write_stage(lds[(j + k) & 1], k);
+          issue_loads(k);                     // item j + k + DEPTH (past the end: the last one again, never used)
+          __syncthreads();                    // item j + k staged; the consumers have drained the other buffer
+        }
+      }
     }
     if (a.stat_partials != nullptr) __syncthreads();   // matches the consumers' barrier in the statistics tail
     return;
@@ -352,19 +386,26 @@ __global__ __launch_bounds__(512, (WINO ? 2 : (NB <= 2 && MODE != 2 ? 4 : 2))) v
     const int pxp = lane & 7, pyl = (lane >> 3) & 1;
     const int lbase = kq * WPLANE + (g0 + 2 * pyl) * WPITCH + pxp;
     const __amdgpu_buffer_rsrc_t rww = make_rsrc(a.wpack, (unsigned)(NB * 16) * (unsigned)(NQ * 16) * 64u);
-    float4 wq[16];
+    float4 wq[WLDS ? 1 : 16];
     auto wsoff = [&](int q_, int xi) { return (unsigned)(((nb0 * NQ + q_) * 16 + xi)) * 1024u; };
+    if (!WLDS) {
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi) wq[xi] = bload4(rww, (unsigned)lane * 16u, wsoff(0, xi));
+      for (int xi = 0; xi < 16; ++xi) wq[xi] = bload4(rww, (unsigned)lane * 16u, wsoff(0, xi));
+    }
 
     f32x4 Y[NGRP][2][2];
 #pragma unroll
     for (int g = 0; g < NGRP; ++g)
 #pragma unroll
       for (int o = 0; o < 4; ++o) Y[g][o >> 1][o & 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto add4 = [](float4 u, float4 v) { return make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w); };
-    auto sub4 = [](float4 u, float4 v) { return make_float4(u.x - v.x, u.y - v.y, u.z - v.z, u.w - v.w); };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto lo2 = [](f32x4 v) { return (f32x2){v[0], v[1]}; };
+    auto hi2 = [](f32x4 v) { return (f32x2){v[2], v[3]}; };
+    auto acc2 = [](f32x4& y, f32x2 l, f32x2 h, bool minus) {
+      const f32x2 yl = minus ? pk_sub((f32x2){y[0], y[1]}, l) : pk_add((f32x2){y[0], y[1]}, l);
+      const f32x2 yh = minus ? pk_sub((f32x2){y[2], y[3]}, h) : pk_add((f32x2){y[2], y[3]}, h);
+      y = (f32x4){yl[0], yl[1], yh[0], yh[1]};
+    };
     int buf = 0, q = 0;
 
     while (true) {
@@ -376,9 +417,11 @@ __global__ __launch_bounds__(512, (WINO ? 2 : (NB <= 2 && MODE != 2 ? 4 : 2))) v
 
       // fused BatchNorm-backward sums of the previous layer (NB == 1 dgrad): its y at this lane's 2x2 output pixels,
       // requested before the MFMA work of the tile's last channel block (see the direct kernel)
+      // (the two-workgroups-per-CU variant has no registers to hold it across the MFMA work: it loads y in the epilogue,
+      // where the other workgroup covers the wait)
       float4 yq[NB == 1 ? 4 : 1];
       float4 bsc = make_float4(0.f, 0.f, 0.f, 0.f), bsh = bsc;
-      if (NB == 1 && bn_stats && last_q) {
+      if (NB == 1 && !WLDS && bn_stats && last_q) {
         int cb_, txi_, tyi_;
         tile_pos(t, cb_, txi_, tyi_);
         const int y0_ = tyi_ * 16 + g0 + 2 * pyl, x0_ = txi_ * 16 + 2 * pxp;
@@ -394,46 +437,73 @@ __global__ __launch_bounds__(512, (WINO ? 2 : (NB <= 2 && MODE != 2 ? 4 : 2))) v
       __builtin_amdgcn_s_setprio(3);
 #pragma unroll
       for (int g = 0; g < NGRP; ++g) {
-        // ---- the patch's 4x4 input window -> V = B^T d B (in place)
-        float4 d[4][4];
+        // ---- the patch's 4x4 input window -> V = B^T d B (in place).  Every float4 is handled as its two aligned
+        // register pairs so that each add / subtract is ONE v_pk_add_f32 (left to itself the compiler pairs components of
+        // different float4s and spends more v_mov than adds assembling the operands)
+        f32x2 dl[4][4], dh[4][4];
         const float4* Lg = L + lbase + g * 4 * WPITCH;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          d[r][0] = Lg[r * WPITCH]; d[r][1] = Lg[r * WPITCH + WHALF]; d[r][2] = Lg[r * WPITCH + 1]; d[r][3] = Lg[r * WPITCH + WHALF + 1];
+          const float4 v0 = Lg[r * WPITCH], v1 = Lg[r * WPITCH + WHALF], v2 = Lg[r * WPITCH + 1], v3 = Lg[r * WPITCH + WHALF + 1];
+          dl[r][0] = (f32x2){v0.x, v0.y}; dh[r][0] = (f32x2){v0.z, v0.w};
+          dl[r][1] = (f32x2){v1.x, v1.y}; dh[r][1] = (f32x2){v1.z, v1.w};
+          dl[r][2] = (f32x2){v2.x, v2.y}; dh[r][2] = (f32x2){v2.z, v2.w};
+          dl[r][3] = (f32x2){v3.x, v3.y}; dh[r][3] = (f32x2){v3.z, v3.w};
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {     // rows: [d0 - d2, d1 + d2, d2 - d1, d1 - d3]
-          const float4 r0 = sub4(d[0][c], d[2][c]), r1 = add4(d[1][c], d[2][c]), r2 = sub4(d[2][c], d[1][c]), r3 = sub4(d[1][c], d[3][c]);
-          d[0][c] = r0; d[1][c] = r1; d[2][c] = r2; d[3][c] = r3;
+          const f32x2 l0 = pk_sub(dl[0][c], dl[2][c]), l1 = pk_add(dl[1][c], dl[2][c]), l2 = pk_sub(dl[2][c], dl[1][c]), l3 = pk_sub(dl[1][c], dl[3][c]);
+          const f32x2 h0 = pk_sub(dh[0][c], dh[2][c]), h1 = pk_add(dh[1][c], dh[2][c]), h2 = pk_sub(dh[2][c], dh[1][c]), h3 = pk_sub(dh[1][c], dh[3][c]);
+          dl[0][c] = l0; dl[1][c] = l1; dl[2][c] = l2; dl[3][c] = l3;
+          dh[0][c] = h0; dh[1][c] = h1; dh[2][c] = h2; dh[3][c] = h3;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {     // columns, same pattern
-          const float4 c0 = sub4(d[r][0], d[r][2]), c1 = add4(d[r][1], d[r][2]), c2 = sub4(d[r][2], d[r][1]), c3 = sub4(d[r][1], d[r][3]);
-          d[r][0] = c0; d[r][1] = c1; d[r][2] = c2; d[r][3] = c3;
+          const f32x2 l0 = pk_sub(dl[r][0], dl[r][2]), l1 = pk_add(dl[r][1], dl[r][2]), l2 = pk_sub(dl[r][2], dl[r][1]), l3 = pk_sub(dl[r][1], dl[r][3]);
+          const f32x2 h0 = pk_sub(dh[r][0], dh[r][2]), h1 = pk_add(dh[r][1], dh[r][2]), h2 = pk_sub(dh[r][2], dh[r][1]), h3 = pk_sub(dh[r][1], dh[r][3]);
+          dl[r][0] = l0; dl[r][1] = l1; dl[r][2] = l2; dl[r][3] = l3;
+          dh[r][0] = h0; dh[r][1] = h1; dh[r][2] = h2; dh[r][3] = h3;
         }
         // ---- per xi-row a: M[b] = U[a][b] * V[a][b] over the 16 channels (4 MFMAs each, 4 independent chains), then
         // t = M A (2 columns) and Y += A^T rows: Y[0] += t for a = 0, 1, 2;  Y[1] += t, -t, -t for a = 1, 2, 3
+        // (software-pipelined by one xi-row: the output transform of row a - 1 is issued behind the MFMAs of row a, so that it
+        // does not sit waiting for results that are still in the matrix pipe)
+        f32x4 M[WLDS ? 1 : 2][4];
+        auto out_row = [&](const int ar, const f32x4 (&Mr)[4]) {
+          // t = M A: t0 = M0 + M1 + M2, t1 = M1 - (M2 + M3).  The FIRST instruction that reads freshly written MFMA results
+          // must be one the compiler knows as a vector-ALU instruction -- it pads the matrix-pipe -> VALU read hazard with
+          // s_nop itself, which it does not do for inline assembly -- hence the plain vector sums (they compile to
+          // v_pk_add_f32); the subtraction then reads M1, whose chain finished before the M2 / M3 ones the sums waited for.
+          const f32x4 t0 = Mr[0] + Mr[1] + Mr[2], u = Mr[2] + Mr[3];
+          const f32x2 t0l = lo2(t0), t0h = hi2(t0);
+          const f32x2 t1l = pk_sub(lo2(Mr[1]), lo2(u)), t1h = pk_sub(hi2(Mr[1]), hi2(u));
+          if (ar <= 2) { acc2(Y[g][0][0], t0l, t0h, false); acc2(Y[g][0][1], t1l, t1h, false); }
+          if (ar == 1) { acc2(Y[g][1][0], t0l, t0h, false); acc2(Y[g][1][1], t1l, t1h, false); }
+          if (ar >= 2) { acc2(Y[g][1][0], t0l, t0h, true); acc2(Y[g][1][1], t1l, t1h, true); }
+        };
 #pragma unroll
         for (int ar = 0; ar < 4; ++ar) {
-          f32x4 M[4];
+          f32x4 (&Mc)[4] = M[WLDS ? 0 : (ar & 1)];
+          float4 wr[4];
 #pragma unroll
-          for (int b = 0; b < 4; ++b) M[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[4 * ar + b].x, d[ar][b].x, zero4, 0, 0, 0);
+          for (int b = 0; b < 4; ++b) wr[b] = WLDS ? wlds[(q * 16 + 4 * ar + b) * 64 + lane] : wq[WLDS ? 0 : 4 * ar + b];
 #pragma unroll
-          for (int b = 0; b < 4; ++b) M[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[4 * ar + b].y, d[ar][b].y, M[b], 0, 0, 0);
+          for (int b = 0; b < 4; ++b) Mc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[b].x, dl[ar][b][0], zero4, 0, 0, 0);
 #pragma unroll
-          for (int b = 0; b < 4; ++b) M[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[4 * ar + b].z, d[ar][b].z, M[b], 0, 0, 0);
+          for (int b = 0; b < 4; ++b) Mc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[b].y, dl[ar][b][1], Mc[b], 0, 0, 0);
 #pragma unroll
-          for (int b = 0; b < 4; ++b) M[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[4 * ar + b].w, d[ar][b].w, M[b], 0, 0, 0);
-          if (g == NGRP - 1) {
+          for (int b = 0; b < 4; ++b) Mc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[b].z, dh[ar][b][0], Mc[b], 0, 0, 0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) Mc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[b].w, dh[ar][b][1], Mc[b], 0, 0, 0);
+          if (!WLDS && g == NGRP - 1) {
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch behind this xi-row's MFMAs (see the direct kernel)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) wq[4 * ar + b] = bload4(rww, (unsigned)lane * 16u, wsoff(qn, 4 * ar + b));
+            for (int b = 0; b < 4; ++b) wq[WLDS ? 0 : 4 * ar + b] = bload4(rww, (unsigned)lane * 16u, wsoff(qn, 4 * ar + b));
           }
-          const f32x4 t0 = M[0] + M[1] + M[2], t1 = M[1] - M[2] - M[3];
-          if (ar <= 2) { Y[g][0][0] += t0; Y[g][0][1] += t1; }
-          if (ar == 1) { Y[g][1][0] += t0; Y[g][1][1] += t1; }
-          if (ar >= 2) { Y[g][1][0] -= t0; Y[g][1][1] -= t1; }
+          if (WLDS) out_row(ar, Mc);
+          else if (ar > 0) out_row(ar - 1, M[WLDS ? 0 : ((ar - 1) & 1)]);
         }
+        if (!WLDS) out_row(3, M[WLDS ? 0 : 1]);
       }
       __builtin_amdgcn_s_setprio(2);
       buf ^= 1;
@@ -463,6 +533,10 @@ __global__ __launch_bounds__(512, (WINO ? 2 : (NB <= 2 && MODE != 2 ? 4 : 2))) v
           }
           bstore4(rd, ok ? pixo * (unsigned)dC * 4u + chb : OOB, 0u, make_float4(v[0], v[1], v[2], v[3]));
           if (NB == 1 && bn_stats) {
+            if (WLDS) {
+              yq[o] = bload4(rby, ok ? pixo * 64u + (unsigned)kq * 16u : OOB, 0u);
+              bsc = ld4(a.bn_scale + 4 * kq); bsh = ld4(a.bn_shift + 4 * kq);
+            }
             const float yy4[4] = {yq[o].x, yq[o].y, yq[o].z, yq[o].w};
             const float scv[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, shv[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
 #pragma unroll
@@ -968,12 +1042,20 @@ __global__ __launch_bounds__(256, 8) void dgrad_border_kernel(const float* __res
 // at most 256 CUs x the residency the kernel variant reaches, and an even split of the tiles.
 bool conv3x3_use_wino(const ConvArgs& a, int cout) {
   static const int off = getenv("SIFSR_NO_WINO") ? atoi(getenv("SIFSR_NO_WINO")) : 0;   // 1: direct kernels everywhere (A/B, debugging)
-  return !off && a.wpack_wino != nullptr && a.bf16 == 0 && cout <= 64 && a.H % 2 == 0 && a.W % 2 == 0;
+  // (16 output channels: the kernel keeps the layer's transform-domain weights in LDS, two channel blocks at most)
+  return !off && a.wpack_wino != nullptr && a.bf16 == 0 && cout <= 64 && a.H % 2 == 0 && a.W % 2 == 0 && (cout > 16 || a.NQ <= 2);
+}
+
+// 0: tap-domain kernel; 1: Winograd, one workgroup per CU; 2: Winograd forward with 16 output channels, two per CU
+int conv3x3_wino_kind(const ConvArgs& a, int cout, int zero_pad) {
+  if (!conv3x3_use_wino(a, cout)) return 0;
+  return (cout == 16 && !zero_pad) ? 2 : 1;
 }
 
 int conv3x3_grid_blocks(int B, int H, int W, int cout, int wino) {
   const int ntiles = B * ((H + 15) / 16) * ((W + 15) / 16);
-  const int per_cu = (wino || cout >= 64) ? 1 : 2;   // residency of the kernel variants (VGPR-limited)
+  const int per_cu = wino ? (wino == 2 ? 2 : 1) : (cout >= 64 ? 1 : 2);   // residency of the kernel variants (VGPR-limited); wino == 2: the
+                                                                            // two-workgroups-per-CU forward variant for 16 output channels
   static const int dbg_grid = getenv("SIFSR_DBG_CONV_GRID") ? atoi(getenv("SIFSR_DBG_CONV_GRID")) : 0;   // tuning knob
   const int gmax = dbg_grid > 0 ? dbg_grid : 256 * per_cu;
   if (ntiles <= gmax) return ntiles;
@@ -1007,7 +1089,7 @@ int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s
     // Winograd F(2x2,3x3) consumers (fp32, <= 64 output channels, even image sizes): a.wpack_wino replaces a.wpack
     ConvArgs w = a;
     w.wpack = a.wpack_wino;
-    const dim3 wgrid(conv3x3_grid_blocks(a.B, a.H, a.W, cout, 1));
+    const dim3 wgrid(conv3x3_grid_blocks(a.B, a.H, a.W, cout, conv3x3_wino_kind(a, cout, zero_pad)));
 #define SIFSR_WINO_LAUNCH(NBV, ZP, DY) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, ZP, 0, DY, true>), wgrid, block, 0, s, w, ntiles, lgx, lgy)
 #define SIFSR_WINO_CASE(NBV)                                                                              \
   case NBV:                                                                                               \

@@ -278,7 +278,7 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
     SIFSR_TRY(launch_conv3x3_mfma(a, L.cout, 0, c.s));
   }
   if (training) {
-    const int nblk = conv3x3_grid_blocks(c.B, a.H, a.W, L.cout, conv3x3_use_wino(a, L.cout));
+    const int nblk = conv3x3_grid_blocks(c.B, a.H, a.W, L.cout, conv3x3_wino_kind(a, L.cout, 0));
     SIFSR_TRY(launch_bn_finalize(c.f(c.lay.partials), nblk, L.cout, (double)c.B * a.H * a.W, c.params + L.gamma_off,
                                  c.params + L.beta_off, running + L.run_off, running + L.run_off + L.cout, momentum, eps,
                                  c.f(c.lay.mean) + L.ch_off, c.f(c.lay.invstd) + L.ch_off,
@@ -385,7 +385,7 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
   if (fuse) {
     a.stat_partials = c.f(c.lay.partials);
     a.bn_y = c.f(c.lay.y[bn_layer]); a.bn_scale = c.scale(bn_layer); a.bn_shift = c.shift(bn_layer);
-    if (stat_rows) *stat_rows = conv3x3_grid_blocks(c.B, a.H, a.W, L.cin, conv3x3_use_wino(a, L.cin));
+    if (stat_rows) *stat_rows = conv3x3_grid_blocks(c.B, a.H, a.W, L.cin, conv3x3_wino_kind(a, L.cin, 1));
   }
   {
     ProfScope ps(l, 2, c.s);

@@ -133,7 +133,7 @@ def test_conv3x3_fwd_dgrad_wgrad(L, case):
     wwf = torch.empty(16 * cin * cout, device="cuda"); wwd = torch.empty(16 * cin * cout, device="cuda")
     L.call("sifsr_pack_conv_weights_wino", dw_, cin, cout, wwf, wwd, S())
     yw = torch.full((B, H, W, cout), float("nan"), device="cuda")
-    nblk_w = L.call("sifsr_conv3x3_stat_blocks_wino", B, H, W, cout)
+    nblk_w = L.call("sifsr_conv3x3_stat_blocks_wino", B, H, W, cin, cout)
     part_w = torch.empty(nblk_w, cout, 2, device="cuda")
     L.call("sifsr_conv3x3_fwd_wino", d0, C0, dsc0, dsh0, d1, C1, dsc1, dsh1, wf, wwf, yw, cout, part_w, B, H, W, S())
     torch.cuda.synchronize()

@@ -9,7 +9,7 @@ cout = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 H = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 B = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 20
-mode = sys.argv[7] if len(sys.argv) > 7 else "fp32"      # fp32 | bf16 | bf16x3 (fwd / dgrad only)
+mode = sys.argv[7] if len(sys.argv) > 7 else "wino"      # wino (fp32, what the model runs) | fp32 (tap-domain kernel) | bf16 | bf16x3 (fwd / dgrad only)
 dev = "cuda"
 torch.manual_seed(0)
 x = torch.randn(B, H, H, cin, device=dev)
@@ -18,6 +18,8 @@ w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5
 wf = torch.empty(9 * cin * cout, device=dev); wd = torch.empty(4 * 9 * cin * cout, device=dev)
 S = torch.cuda.current_stream().cuda_stream
 L.call("sifsr_pack_conv_weights", w, cin, cout, wf, wd, S)
+wwf = torch.empty(16 * cin * cout, device=dev); wwd = torch.empty(16 * cin * cout, device=dev)
+L.call("sifsr_pack_conv_weights_wino", w, cin, cout, wwf, wwd, S)
 y = torch.empty(B, H, H, cout, device=dev)
 part = torch.empty(B * (H // 16) * (H // 16) * cout * 2, device=dev)
 dy = torch.randn(B, H, H, cout, device=dev)
@@ -26,7 +28,11 @@ nblk = int(os.environ.get("NBLK", 2048 if 9 * cin * cout <= 4608 else 1024))
 scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_scratch_floats", cin, cout, nblk), device=dev)
 dw = torch.empty_like(w)
 def run():
-    if op == "fwd" and mode == "fp32":
+    if op == "fwd" and mode == "wino":
+        L.call("sifsr_conv3x3_fwd_wino", x, cin, sc, sh, None, 0, None, None, wf, wwf, y, cout, part, B, H, H, S)
+    elif op == "dgrad" and mode == "wino":
+        L.call("sifsr_conv3x3_dgrad_wino", dy, cout, wd, wwd, cin, g, cin, None, 0, None, B, H, H, S)
+    elif op == "fwd" and mode == "fp32":
         L.call("sifsr_conv3x3_fwd", x, cin, sc, sh, None, 0, None, None, wf, y, cout, part, B, H, H, S)
     elif op == "fwd":
         L.call("sifsr_conv3x3_fwd_" + mode, x, cin, sc, sh, None, 0, None, None, wd, y, cout, part, B, H, H, S)
