@@ -1085,6 +1085,23 @@ int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s
   const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
   const bool dyf = a.bw_y != nullptr;
   if (dyf && (!zero_pad || !a.bw_coef || a.src[1].ptr || a.src[0].scale || a.src[0].coff)) return SIFSR_ERR_ARG;
+  if (nb == 8 && conv3x3_use_wino(a, 64) && a.stat_partials == nullptr && a.dst_split % 4 == 0) {
+    // 128 output channels (the input gradient of ub1.convbloc.bloc.0): two Winograd launches of 64 channels each -- the
+    // weight pack is [cout block][cin block][xi], so the second half is a pointer offset; each half lies in one destination
+    for (int h = 0; h < 2; ++h) {
+      ConvArgs w = a;
+      w.wpack_wino = a.wpack_wino + (size_t)h * 4 * a.NQ * 16 * 256;
+      const bool first = 4 * h < a.dst_split;
+      w.dst[0] = first ? a.dst[0] : a.dst[1];
+      w.dst[0].coff += first ? 64 * h : 16 * (4 * h - a.dst_split);
+      w.dst[1] = w.dst[0];
+      w.dst_split = 4;
+      if (a.addend != nullptr) w.addend = a.addend + 64 * h;
+      const int rc = launch_conv3x3_mfma(w, 64, zero_pad, s);
+      if (rc != SIFSR_OK) return rc;
+    }
+    return SIFSR_OK;
+  }
   if (conv3x3_use_wino(a, cout)) {
     // Winograd F(2x2,3x3) consumers (fp32, <= 64 output channels, even image sizes): a.wpack_wino replaces a.wpack
     ConvArgs w = a;
