@@ -262,5 +262,9 @@ SIFSR_API int sifsr_set_wgrad_stream(int on);
  * sifsr_profile_read synchronises the recorded events and returns their summed duration and count. */
 SIFSR_API int sifsr_profile_select(int layer, int phase);
 SIFSR_API int sifsr_profile_read(float* total_ms, int* count);
+/* Several kernels side by side: sifsr_profile_select(l, p) makes slot 0, each sifsr_profile_add one more (returns the
+ * slot, < 0 when the 8 slots are used); all event pairs are created by these calls, outside the caller's timed region. */
+SIFSR_API int sifsr_profile_add(int layer, int phase);
+SIFSR_API int sifsr_profile_read_slot(int slot, float* total_ms, int* count);
 
 #endif /* SIFSR_HIP_H */

@@ -397,7 +397,9 @@ int sifsr_adam_flat(float* params, const float* grads, float* exp_avg, float* ex
 
 int sifsr_set_wgrad_stream(int on) { return sifsr_engine_set_wgrad_stream(on); }
 int sifsr_profile_select(int layer, int phase) { return sifsr_engine_profile_select(layer, phase); }
-int sifsr_profile_read(float* total_ms, int* count) { return sifsr_engine_profile_read(total_ms, count); }
+int sifsr_profile_read(float* total_ms, int* count) { return sifsr_engine_profile_read(0, total_ms, count); }
+int sifsr_profile_add(int layer, int phase) { return sifsr_engine_profile_add(layer, phase); }
+int sifsr_profile_read_slot(int slot, float* total_ms, int* count) { return sifsr_engine_profile_read(slot, total_ms, count); }
 
 // ---- input pipeline / metrics ----
 int sifsr_tiles_prepare(const float* lst, const float* ndvi, float* x, int tiles_y, int tiles_x, int win, int lst_h, int lst_w,

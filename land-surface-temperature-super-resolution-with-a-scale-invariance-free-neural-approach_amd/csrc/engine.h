@@ -38,4 +38,5 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
                           size_t ws_floats, int B, int H, int W, hipStream_t s, int bf16 = 0);
 int sifsr_engine_set_wgrad_stream(int on);   // 1 / 0: weight gradients on their own stream or not; -1: SIFSR_WGRAD_STREAM / default (on)
 int sifsr_engine_profile_select(int layer, int phase);
-int sifsr_engine_profile_read(float* total_ms, int* count);
+int sifsr_engine_profile_add(int layer, int phase);
+int sifsr_engine_profile_read(int slot, float* total_ms, int* count);

@@ -229,29 +229,42 @@ struct SideLaneGuard {
 
 // ---- optional per-kernel timing (bench.py roofline): HIP events on the launch stream around ONE
 // selected (layer, phase) launch inside the normal schedule.  phase 1 fwd conv, 2 dgrad, 3 wgrad.
-// The event pairs are created by sifsr_engine_profile_select (i.e. before the caller's timed region), never inside a
-// launch; a launch that finds the pool exhausted is simply not timed.  One mutex serialises selection, use and read.
-struct ProfState {
+// Up to PROF_SLOTS (layer, phase) selections are timed side by side.  The event pairs are created by
+// sifsr_engine_profile_select / _add (i.e. before the caller's timed region), never inside a launch; a launch that finds
+// its pool exhausted is simply not timed.  One mutex serialises selection, use and read.
+constexpr int PROF_SLOTS = 8;
+constexpr size_t PROF_POOL = 1024;   // launches of one selected kernel that can be timed before the next select
+struct ProfSlot {
   int layer = -1, phase = 0;
   std::vector<hipEvent_t> start, stop;   // the pool
   size_t used = 0;
+};
+struct ProfState {
+  ProfSlot slot[PROF_SLOTS];
+  int active = 0;                        // number of slots in use (0: profiling off, the common case)
   std::mutex mu;
 };
 ProfState g_prof;
 
 struct ProfScope {
-  hipStream_t s; long idx = -1;
+  hipStream_t s; int sl = -1; long idx = -1;
   ProfScope(int layer, int phase, hipStream_t st) : s(st) {
-    if (g_prof.layer < 0) return;   // unlocked fast path: profiling is off (the common case)
+    if (g_prof.active == 0) return;   // unlocked fast path
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    if (layer != g_prof.layer || phase != g_prof.phase || g_prof.used >= g_prof.start.size()) return;
-    idx = (long)g_prof.used++;
-    (void)hipEventRecord(g_prof.start[idx], s);
+    for (int k = 0; k < g_prof.active; ++k) {
+      ProfSlot& p = g_prof.slot[k];
+      if (p.layer == layer && p.phase == phase && p.used < p.start.size()) {
+        sl = k; idx = (long)p.used++;
+        (void)hipEventRecord(p.start[idx], s);
+        return;
+      }
+    }
   }
   ~ProfScope() {
     if (idx < 0) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    if ((size_t)idx < g_prof.stop.size()) (void)hipEventRecord(g_prof.stop[idx], s);
+    ProfSlot& p = g_prof.slot[sl];
+    if ((size_t)idx < p.stop.size()) (void)hipEventRecord(p.stop[idx], s);
   }
 };
 
@@ -599,28 +612,38 @@ int sifsr_engine_set_wgrad_stream(int on) {
   return SIFSR_OK;
 }
 
-int sifsr_engine_profile_select(int layer, int phase) {
-  std::lock_guard<std::mutex> lk(g_prof.mu);
-  const size_t pool = 4096;   // launches of the selected kernel that can be timed before the next select
-  g_prof.layer = -1;
-  if (layer >= 0) {
-    while (g_prof.start.size() < pool) {
-      hipEvent_t e0, e1;
-      if (hipEventCreate(&e0) != hipSuccess) break;
-      if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); break; }
-      g_prof.start.push_back(e0); g_prof.stop.push_back(e1);
-    }
+static int prof_add_locked(int layer, int phase) {
+  if (g_prof.active >= PROF_SLOTS) return -1;
+  ProfSlot& p = g_prof.slot[g_prof.active];
+  while (p.start.size() < PROF_POOL) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) break;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); break; }
+    p.start.push_back(e0); p.stop.push_back(e1);
   }
-  g_prof.used = 0;
-  g_prof.phase = phase; g_prof.layer = layer;
+  p.used = 0; p.layer = layer; p.phase = phase;
+  return g_prof.active++;
+}
+int sifsr_engine_profile_select(int layer, int phase) {   // layer < 0: profiling off; else exactly this one selection (slot 0)
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.active = 0;
+  if (layer >= 0 && prof_add_locked(layer, phase) < 0) return SIFSR_ERR_ARG;
   return SIFSR_OK;
 }
-int sifsr_engine_profile_read(float* total_ms, int* count) {
+int sifsr_engine_profile_add(int layer, int phase) {      // one more selection next to the existing ones; returns its slot or < 0
+  if (layer < 0) return -1;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  return prof_add_locked(layer, phase);
+}
+int sifsr_engine_profile_read(int slot, float* total_ms, int* count) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   float tot = 0.f; int n = 0;
-  for (size_t i = 0; i < g_prof.used; ++i) {
-    float ms = 0.f;
-    if (hipEventSynchronize(g_prof.stop[i]) == hipSuccess && hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]) == hipSuccess) { tot += ms; ++n; }
+  if (slot >= 0 && slot < g_prof.active) {
+    ProfSlot& p = g_prof.slot[slot];
+    for (size_t i = 0; i < p.used; ++i) {
+      float ms = 0.f;
+      if (hipEventSynchronize(p.stop[i]) == hipSuccess && hipEventElapsedTime(&ms, p.start[i], p.stop[i]) == hipSuccess) { tot += ms; ++n; }
+    }
   }
   if (total_ms) *total_ms = tot;
   if (count) *count = n;
