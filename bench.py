@@ -68,7 +68,8 @@ WINOGRAD = {"fwd_16x16_256", "dgrad_16x16_256", "fwd_32x16_256", "dgrad_32x16_25
 
 def dominant_kernel():
     """The roofline kernel whose kernel CLASS has the largest time share in the newest committed rocprofv3 kernel-stats file."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.csv")), key=os.path.getmtime)
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.csv")) if "single" not in os.path.basename(f)),
+                   key=os.path.getmtime)   # profiles of THIS command (default two-stream backward), not the single-stream diagnostics
     for f in reversed(files):
         try:
             rows = list(csv.DictReader(open(f)))
@@ -236,6 +237,30 @@ def main():
         L.call("sifsr_profile_read_slot", slot, ctypes.byref(kms), ctypes.byref(kcount))
         ktimes[name] = (kms.value / max(1, kcount.value), kcount.value)
     L.call("sifsr_profile_select", -1, 0)
+    # The weight-gradient kernels run on the library's second stream BESIDE the rest of the backward pass, so their in-step
+    # duration is that of a kernel sharing the machine.  A few extra, untimed steps with the single-stream schedule give the
+    # same launches' stand-alone durations, reported next to the in-step ones (`solo_ms`).
+    ksolo = {}
+    if timed:
+        L.call("sifsr_set_wgrad_stream", 0)
+        try:
+            step()
+            for j, (name, _) in enumerate(timed):
+                layer, phase, _, _ = ROOFLINE_KERNELS[name]
+                if j == 0:
+                    L.call("sifsr_profile_select", layer, phase)
+                else:
+                    L.call("sifsr_profile_add", layer, phase)
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            for name, slot in timed:
+                kms, kcount = ctypes.c_float(0), ctypes.c_int(0)
+                L.call("sifsr_profile_read_slot", slot, ctypes.byref(kms), ctypes.byref(kcount))
+                ksolo[name] = kms.value / max(1, kcount.value)
+        finally:
+            L.call("sifsr_profile_select", -1, 0)
+            L.call("sifsr_set_wgrad_stream", -1)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -281,8 +306,13 @@ def main():
             kern = {}
             for name, (avg_ms, n) in ktimes.items():
                 tf = ROOFLINE_KERNELS[name][2] * batch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+                solo = ksolo.get(name, 0.0)
+                tf_solo = ROOFLINE_KERNELS[name][2] * batch / (solo * 1e-3) / 1e12 if solo > 0 else 0.0
                 kern[name] = {"avg_ms": round(avg_ms, 4), "launches_timed": n, "achieved": round(tf, 2),
                               "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                              "solo_ms": round(solo, 4), "solo_frac": round(tf_solo / PEAK_FP32_MFMA_TFLOPS, 4),
+                              "concurrent": "runs on the second stream beside the input-gradient chain" if name.startswith("wgrad") else
+                                            ("shares the machine with the previous layer's weight gradient" if name.startswith("dgrad") else "alone"),
                               "algorithm": "winograd F(2x2,3x3): 4/9 of the algorithmic MACs executed" if name in WINOGRAD else "direct"}
             traffic, traffic_src = measured_traffic(dom)
             k = kern[dom]
@@ -291,6 +321,7 @@ def main():
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": k["frac"], "traffic": traffic,
                 "traffic_unit": "HBM bytes/launch (PMC)", "traffic_source": traffic_src,
                 "kernel_avg_ms": k["avg_ms"], "kernel_launches_timed": k["launches_timed"], "algorithm": k["algorithm"],
+                "solo_ms": k["solo_ms"], "solo_frac": k["solo_frac"], "concurrent": k["concurrent"],
                 "kernels": kern, "step": step_obj,
             }
         else:
