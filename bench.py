@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--roofline-kernel", default="auto", choices=["auto"] + sorted(ROOFLINE_KERNELS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-solo", action="store_true", help="skip the extra single-stream steps that time the selected kernels alone "
+                                                            "(profiling runs: keeps the kernel trace to the steps of the benchmark itself)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16x3"],
                     help="f32 = the headline fp32 path; bf16 = BASELINE.json config 5 (bf16 MFMA operands in the 3x3 conv "
                          "forward / input-gradient / weight-gradient passes, fp32 accumulation and storage); bf16x3 = fp32 on the bf16 "
@@ -241,7 +243,7 @@ def main():
     # duration is that of a kernel sharing the machine.  A few extra, untimed steps with the single-stream schedule give the
     # same launches' stand-alone durations, reported next to the in-step ones (`solo_ms`).
     ksolo = {}
-    if timed:
+    if timed and not args.no_solo:
         L.call("sifsr_set_wgrad_stream", 0)
         try:
             step()
