@@ -3,21 +3,25 @@
 // Replaces what the reference dispatches to ATen/MKLDNN/cuDNN for nn.Conv2d(k=3, padding=1,
 // padding_mode='replicate', bias=False) -- model.py:135,138,507 -- and its input-gradient.
 //
-// Mapping (one workgroup = 256 threads = 4 waves; PERSISTENT: it walks 16x16-pixel output tiles and
-// prefetches the next tile's halo into registers while the matrix cores work on the current one):
-//   * the (16+2)x(16+2) input halo tile of one 16-channel block is staged in LDS as
-//     [channel-quad k][pixel][4 channels]  (plane stride 336 pixels = 0 mod 16 slots), with the
-//     producing layer's BatchNorm+ReLU folded into the staging (relu(x*scale+shift));
-//   * v_mfma_f32_16x16x4_f32: A = weights (16 cout x 4 cin), B = activations (4 cin x 16 pixels of
-//     one image row), D = 16 cout x 16 pixels.  Lane (i = lane&15, k = lane>>4) reads ONE
-//     ds_read_b128 = channels 4k..4k+3 of pixel i and feeds 4 MFMAs (k-step j uses channel 4k+j on
-//     both operands -- the contraction order inside a 16-channel block is a free permutation);
-//     this read is bank-conflict free;
-//   * weights come pre-packed in fragment order (pack_weights_kernel): one coalesced
-//     global_load_dwordx4 per (cout block, cin block, tap) per wave, L2 resident;
-//   * D rows are 4 consecutive cout per lane -> one 16-byte NHWC store per lane per tile row;
-//   * optional epilogue: per-channel (sum, sumsq) of the tile for training-mode BatchNorm statistics,
-//     reduced with wave shuffles + LDS and written per workgroup (deterministic 2-stage reduction).
+// Mapping (one workgroup = 512 threads = 8 waves, four PRODUCERS and four CONSUMERS; PERSISTENT: it walks 16x16-pixel output
+// tiles in an XCD-aware order; see the role comment above the kernel):
+//   * the (16+2)x(16+2) input halo tile of one 16-channel block is staged in LDS by the producers as
+//     [channel-quad k][pixel][4 channels], with the producing layer's BatchNorm+ReLU folded into the staging
+//     (relu(x*scale+shift)) -- or, in the input-gradient pass, the BatchNorm+ReLU BACKWARD of the layer itself (DYF: dL/dy is
+//     formed from (g, y) here and never stored);
+//   * tap-domain consumers: v_mfma_f32_16x16x4_f32, A = weights (16 cout x 4 cin), B = activations (4 cin x 16 pixels of
+//     one image row), D = 16 cout x 16 pixels.  Lane (i = lane&15, k = lane>>4) reads ONE ds_read_b128 = channels 4k..4k+3 of
+//     pixel i and feeds 4 MFMAs (k-step j uses channel 4k+j on both operands -- the contraction order inside a 16-channel
+//     block is a free permutation); this read is bank-conflict free;
+//   * Winograd consumers (WINO; what the fp32 model runs for <= 64 output channels): the same lane map with the 16
+//     transform-domain positions of a 2x2 output patch in the place of the 9 taps of a pixel -- 4/9 of the MFMAs, the input
+//     and output transforms as packed adds on the operand / accumulator registers;
+//   * weights come pre-packed in fragment order (pack_weights_kernel / pack_wino_kernel): one coalesced
+//     buffer_load_dwordx4 per (cout block, cin block, tap or xi) per wave, L2 resident;
+//   * D rows are 4 consecutive cout per lane -> one 16-byte NHWC store per lane per pixel;
+//   * optional epilogue: per-channel (sum, sumsq) of the tile for training-mode BatchNorm statistics (or, for 16-channel
+//     input gradients, the BatchNorm-backward sums of the layer below), reduced with wave shuffles + LDS and written per
+//     workgroup (deterministic 2-stage reduction), residual addend, split destinations.
 #include "conv.h"
 
 #include <stdlib.h>
