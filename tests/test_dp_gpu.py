@@ -112,3 +112,48 @@ def test_two_rank_step_matches_micro_batched_single_process(tmp_path, kind, keep
     # the parameters must agree: the all-reduce adds the same two fp32 gradient buffers this loop adds, and every kernel
     # is deterministic.  (keep_grads: zero_grad(set_to_none=False) zeroes and autograd adds -> same values)
     assert torch.allclose(a, ref, rtol=0, atol=5e-6)
+
+
+RCCL_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["SIFSR_ROOT"])
+import torch.distributed as dist
+import sifsr
+from sifsr import distributed as dp
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+torch.manual_seed(3)
+model = sifsr.ModelB_2(2, [16, 32, 64, 128], "replicate", "ReLU", 1, 1).cuda()
+opt = sifsr.FlatAdam(model.parameters(), lr=1e-3)
+dp.broadcast_parameters(model, opt, src=0)                     # ncclBroadcast of the flat buffers
+stats = dict(sifsr.dataset.DEFAULT_STATS)
+lst, lst_up, ndvi = sifsr.dataset.synthetic_device_batch(2, "cuda", seed=5)
+model.train(); opt.zero_grad(set_to_none=True)
+sr = model(torch.cat((lst_up, ndvi), 1))
+_, _, loss = sifsr.sif_loss("sr2", sr, lst, ndvi, stats["mean_lst"], stats["std_lst"], 0.5, -0.25)
+loss.backward()
+g0 = model.flat_grad().clone()
+flat = model.flat_grad()
+dp._sum_all_reduce_(flat)                                      # ncclAllReduce(sum) over the 1.13 MB gradient bucket
+torch.cuda.synchronize()
+assert dist.get_backend() == "nccl" and torch.equal(flat, g0) and flat.numel() == 282705
+dp.broadcast_buffers(model, src=0)
+opt.step(); torch.cuda.synchronize()
+print("rccl single-rank ok", float(loss))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_rccl_backend_single_rank(tmp_path):
+    """RCCL needs one GPU per rank, so the multi-rank exchange cannot run on a one-GPU box; what can is the backend
+    itself: a world of ONE rank on backend "nccl" (= RCCL on ROCm) creates the communicator and runs the very calls of
+    the data-parallel step -- ncclBroadcast of the flat parameter / optimizer buffers, ncclAllReduce(sum) of the flat
+    282,705-float gradient, the buffer broadcast -- on device memory, and must leave the values unchanged."""
+    env = dict(os.environ, SIFSR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rccl single-rank ok" in r.stdout
