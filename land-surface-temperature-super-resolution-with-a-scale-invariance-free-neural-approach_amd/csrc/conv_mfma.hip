@@ -219,11 +219,10 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
     // One item in flight: the loads of item j+1 are issued right after item j went to LDS and land while the
     // consumers work on item j.  (Two register sets / two items in flight measured 4 % slower: the consumers,
     // not the load latency, are the critical path.)
-    // WINO (one workgroup per CU, items half as long): DEPTH register sets = DEPTH items in flight, so that the loads of
-    // item j + DEPTH are issued when item j goes to LDS and have DEPTH item times to land (HBM latency under load is 2-3 us,
-    // a Winograd item ~2 us).  The two-workgroups-per-CU variants (direct; Winograd with 16 output channels) keep one set:
-    // the workgroups cover each other and the registers are needed elsewhere.
-    constexpr int DEPTH = (WINO && !WLDS) ? (DYF ? 2 : 3) : 1;
+    // DEPTH register sets = DEPTH items in flight: the loads of item j + DEPTH are issued when item j goes to LDS.  One is
+    // enough everywhere: with two or three sets the one-workgroup-per-CU Winograd variants (whose items are half as long)
+    // measured the same to 0.2 % -- what they wait for is not load latency.
+    constexpr int DEPTH = 1;
     float4 stgS[DEPTH][6], scS[DEPTH], shS[DEPTH];
     float4 styS[DYF ? DEPTH : 1][DYF ? 6 : 1], k1S[DEPTH], k0S[DEPTH];   // DYF: y of the same slots, two more coefficient quads
     bool rawS[DEPTH];
