@@ -57,7 +57,9 @@ static int wgrad_blocks(int cin, int cout, int chunks, int ntiles) {
   // workgroup so that the slab write + slab reduction stay small next to the MFMA work (measured per layer).
   // (re-swept with the weight gradients on the second stream: smaller grids leave the chain more room but lose more
   // than they give -- 1024 / 512 stay)
-  const int total = (cin == 16 && cout == 16) ? 1024 : 512;
+  static const int dbg_scale = getenv("SIFSR_DBG_WGRAD_GRID_PCT") ? atoi(getenv("SIFSR_DBG_WGRAD_GRID_PCT")) : 100;   // tuning knob
+  // (round 2, beside the Winograd chain -- one workgroup per CU, registers to spare: 1.5x the round-1 grids, +1 %; flat to 2.5x)
+  const int total = ((cin == 16 && cout == 16) ? 1536 : 768) * dbg_scale / 100;
   int n = total / chunks;
   if (n < 64) n = 64;
   const int cap = ntiles / 4 > 0 ? ntiles / 4 : 1;
