@@ -155,3 +155,58 @@ def test_dropin_modules_cover_the_reference_scripts_names():
             elif isinstance(node, ast.Assign):
                 defined.update(t.id for t in node.targets if isinstance(t, ast.Name))
         assert names <= defined, (mod, names - defined)
+
+
+def test_dropin_utils_host_functions(golden, tmp_path):
+    """The host-only half of dropin/utils.py (no GPU): read_JsonB on a paramsB.json-shaped file (utils.py:741-764 order of
+    the returned tuple), generate_psf_kernel against the reference's 9x9 kernels (golden), model_checkpoint's early-stopping
+    sequence (utils.py:667-714), and the loud refusal of the out-of-scope GDAL functions."""
+    import importlib
+    import json
+    import os
+    import sys
+    import numpy as np
+    import pytest
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    saved = {k: sys.modules.pop(k, None) for k in ("model", "dataset", "utils")}
+    sys.path.insert(0, os.path.join(root, "dropin"))
+    try:
+        us = importlib.import_module("utils")
+        params = {"dataset_parameter": {"time": "day", "transf": "norm"},
+                  "hyperparameters": {"batch_size": 8, "learning_rate": 0.001, "n_epochs": 200, "patience": 30, "alpha": 0.1, "gamma": -0.4},
+                  "modelA_parameters": {"in_channels": 1}, "modelB_parameters": {"in_channels": 2, "downchannels": [16, 32, 64, 128],
+                  "padding_mode": "replicate", "activation": "ReLU", "bilinear": 1, "n_bridge_blocks": 1},
+                  "save_parameters": {"model_name": "modelB", "save_path": "./models/modelB_test"}, "device": "cpu"}
+        f = tmp_path / "paramsB.json"
+        f.write_text(json.dumps(params))
+        ds, ma, mb, hy, sv, dev = us.read_JsonB(str(f))
+        assert (ds, ma, mb, hy, sv, dev) == (params["dataset_parameter"], params["modelA_parameters"], params["modelB_parameters"],
+                                             params["hyperparameters"], params["save_parameters"], "cpu")
+        for mtf in (0.1, 0.25):
+            k = us.generate_psf_kernel(1.0, 4, mtf, None)
+            ref = np.array(golden["cases"][f"psf_{mtf}"]["kernel9x9"], dtype=np.float32).reshape(9, 9)
+            assert k.dtype == np.float32 and np.abs(k - ref).max() < 2e-8       # outer product of the taps vs the 2-D formula
+        # early stopping: improvement resets the counter; `>=` counts as no improvement; patience 2 breaks at the 2nd miss
+        m = torch.nn.Linear(2, 2)
+        ck = us.model_checkpoint(10, patience=2)
+        metrics = {"val_loss": []}
+        states = []
+        for epoch, v in enumerate([1.0, 0.8, 0.8, 0.9], start=1):
+            metrics["val_loss"].append(v)
+            ck.test_update(m, metrics, "val_loss", epoch)
+            states.append((ck.best_epoch, ck.curr_patience, ck.train_state))
+        assert states == [(1, 0, None), (2, 0, "continue"), (2, 1, "continue"), (2, 2, "break")]
+        assert set(ck.saved_state) == {"weight", "bias"}
+        ck = us.model_checkpoint(2, patience=5)                                  # last epoch with a non-zero counter: break
+        ck.test_update(m, {"val_loss": [1.0]}, "val_loss", 1)
+        ck.test_update(m, {"val_loss": [1.0, 1.5]}, "val_loss", 2)
+        assert ck.train_state == "break" and ck.best_epoch == 1
+        with pytest.raises(NotImplementedError, match="read_NIRRED"):
+            us.read_NIRRED("x.hdf")
+    finally:
+        sys.path.remove(os.path.join(root, "dropin"))
+        for k, v in saved.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
