@@ -176,6 +176,29 @@ def main():
             "kind": kind, "alpha": alpha, "gamma": gamma, "wseed": wseed, "bseed": bseed, "B": B, "mask_seed": 500 + wseed,
             "sr": O.digest(r[0]), "ds": r[1][0], "pl": r[1][1], "loss": r[1][2],
             "grads": {n: O.digest(g, 8) for n, g in r[2].items()}, "oracle_vs_reference_worst_rel": worst}
+    # ------------------------------------------------------------------------------------------
+    # 3. early stopping: sifsr.train.ModelCheckpoint against the reference's us.model_checkpoint (utils.py:667-714) on
+    #    random validation-loss sequences (generator-time assertion; host-side bookkeeping, nothing to store)
+    # ------------------------------------------------------------------------------------------
+    import random
+    import sifsr  # noqa: F401  (CPU import: the HIP library is only loaded on first use)
+    from sifsr.train import ModelCheckpoint
+    random.seed(1)
+    lin = torch.nn.Linear(1, 1)
+    for _ in range(300):
+        n, pat = random.randint(1, 12), random.randint(1, 5)
+        a, b = ref_utils.model_checkpoint(n, pat), ModelCheckpoint(n, pat)
+        hist = {"v": []}
+        for e in range(1, n + 1):
+            hist["v"].append(round(random.random(), 1))
+            a.test_update(lin, hist, "v", e); b.test_update(lin, hist, "v", e)
+            assert (a.best_epoch, a.curr_patience, a.train_state, a.saved_best_value) == \
+                   (b.best_epoch, b.curr_patience, b.train_state, b.saved_best_value), (hist, pat, e)
+            if a.train_state == "break":
+                break
+    print("ModelCheckpoint == reference model_checkpoint on 300 random sequences")
+    out["model_checkpoint_checked_sequences"] = 300
+
     path = os.path.join(HERE, "golden_masked_v1.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
