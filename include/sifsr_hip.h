@@ -185,6 +185,12 @@ SIFSR_API int sifsr_bnrelu_add(const float* p, const float* y, const float* scal
 SIFSR_API int sifsr_bnrelu_up2x(const float* y, const float* scale, const float* shift, float* out, int B, int Hin, int Win, int C, void* stream); /* Upsample(x2,bilinear,align_corners=True), model.py:207 */
 SIFSR_API int sifsr_pool2_bwd(const float* gp, float* g, int B, int H, int W, int C, int accumulate, void* stream);
 SIFSR_API int sifsr_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, void* stream);
+/* The same adjoint when g is the complete gradient w.r.t. relu(bn(y)) of the low-resolution layer (the decoder inputs of
+ * ModelB_2): also leaves that layer's BatchNorm-backward sums, one row [C][2] = (sum dz, sum dz*y) per workgroup,
+ * dz = g*[y*scale + shift > 0], in partials (sifsr_up2x_bwd_stat_rows() rows; 0 = shape not served, C in {16, 32, 64}). */
+SIFSR_API int sifsr_up2x_bwd_stat_rows(int B, int Hin, int Win, int C);
+SIFSR_API int sifsr_up2x_bwd_bn_sums(const float* gu, float* g, int B, int Hin, int Win, int C, const float* y,
+                                     const float* scale, const float* shift, float* partials, void* stream);
 
 /* ---- SIF loss operators on (B,1,H,W) images --------------------------------------------------- */
 /* taps9: 9 HOST floats, the separable factor of generate_psf_kernel (utils.py:1615-1639) */

@@ -356,6 +356,12 @@ int sifsr_bnrelu_up2x(const float* y, const float* scale, const float* shift, fl
 int sifsr_pool2_bwd(const float* gp, float* g, int B, int H, int W, int C, int accumulate, void* stream) {
   return launch_pool2_bwd(gp, g, B, H, W, C, accumulate, S(stream));
 }
+int sifsr_up2x_bwd_stat_rows(int B, int Hin, int Win, int C) { return up2x_bwd_stat_rows(B, Hin, Win, C); }
+int sifsr_up2x_bwd_bn_sums(const float* gu, float* g, int B, int Hin, int Win, int C, const float* y, const float* scale,
+                           const float* shift, float* partials, void* stream) {
+  if (!y || !scale || !shift || !partials) return SIFSR_ERR_ARG;
+  return launch_up2x_bwd(gu, g, B, Hin, Win, C, S(stream), y, scale, shift, partials);
+}
 int sifsr_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, void* stream) {
   return launch_up2x_bwd(gu, g, B, Hin, Win, C, S(stream));
 }

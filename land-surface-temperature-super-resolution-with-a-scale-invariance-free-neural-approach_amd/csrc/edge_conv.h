@@ -52,7 +52,11 @@ int launch_bnrelu_pool2(const float* y, const float* scale, const float* shift, 
 int launch_bnrelu_add(const float* p, const float* y, const float* scale, const float* shift, float* out, int C, size_t npix, hipStream_t s);
 int launch_bnrelu_up2x(const float* y, const float* scale, const float* shift, float* out, int B, int Hin, int Win, int C, hipStream_t s);
 int launch_pool2_bwd(const float* gp, float* g, int B, int H, int W, int C, int accumulate, hipStream_t s);
-int launch_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, hipStream_t s);
+// bn_partials != nullptr: also the BatchNorm-backward sums (sum dz, sum dz*y) of the low-resolution layer whose gradient g is,
+// one row of [C][2] per workgroup, up2x_bwd_stat_rows() rows (0: the tiled kernel does not serve this shape)
+int launch_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, hipStream_t s, const float* bn_y = nullptr,
+                    const float* bn_scale = nullptr, const float* bn_shift = nullptr, float* bn_partials = nullptr);
+int up2x_bwd_stat_rows(int B, int Hin, int Win, int C);
 
 // ---- adam.hip ----
 int launch_adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, float beta1, float beta2, float eps,

@@ -14,6 +14,7 @@ struct WsLayout {
   size_t y[SIFSR_NUM_BN_LAYERS];          // raw conv outputs (pre-BN), NHWC
   size_t P[3], R[3], U[3];                // pooled inputs, residual sums, upsampled decoder inputs
   size_t partials;                        // BN statistic partials (scratch)
+  size_t partials_cap;                    // its size in floats
   size_t fwd_end;
   size_t coef;                            // BN-backward affine coefficients (3 x C float64, current layer: fused head / tail)
   size_t coef_f;                          // bn_bwd4 coefficients of every layer, [4][C] fp32 at 4 * ch_off (kept for the whole backward:

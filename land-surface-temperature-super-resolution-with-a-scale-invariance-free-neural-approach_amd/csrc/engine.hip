@@ -99,7 +99,14 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
     const size_t n = (nblk > 1024 ? nblk : 1024) * nt.L[l].cout * 2;
     maxpart = n > maxpart ? n : maxpart;
   }
+  // ... and the upsample adjoints' rows (one per 8x8 low-resolution pixels and image) for the three decoder inputs
+  for (int k = 0; k < 3; ++k) {
+    const int lh = H >> (3 - k), lw = W >> (3 - k);
+    const size_t n = (size_t)up2x_bwd_stat_rows(B, lh, lw, 64 >> k) * (64 >> k) * 2;
+    maxpart = n > maxpart ? n : maxpart;
+  }
   w.partials = take(maxpart);
+  w.partials_cap = maxpart;
   w.fwd_end = off;
   if (training) {
     w.coef = take(6 * 64);   // 3 x C float64 BN-backward coefficients of the layer being processed
@@ -308,14 +315,16 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
 // gp != nullptr: g is first completed by the AvgPool adjoint of the half-resolution gradient gp, in place (bn.hip PoolAdj).
 // fused_stats > 0: the sums were already produced by the dgrad (fused_stats = its workgroup count) + border kernel of the
 // layer above (conv_unit_dgrad with bn_layer), so the reduce pass over (g, y) is skipped.
-int bn_unit_bwd(const Ctx& c, int l, float* g, float* grads, const float* gp = nullptr, int fused_stats = 0) {
+// border_rows: rows the border-fold kernel added to bpart (default: those of a 16-channel dgrad); 0 when the sums came
+// from the upsample adjoint (resample.hip), which has no border part.
+int bn_unit_bwd(const Ctx& c, int l, float* g, float* grads, const float* gp = nullptr, int fused_stats = 0, int border_rows = -1) {
   const LayerInfo& L = c.nt.L[l];
   const int lh = c.lvH(L.level), lw = c.lvW(L.level);
   const size_t npix = c.lay.npix[L.level];
   float* coef_f = c.f(c.lay.coef_f) + 4 * (size_t)L.ch_off;
   if (fused_stats > 0) {
     if (gp != nullptr) return SIFSR_ERR_ARG;
-    return launch_bn_bwd_finalize2(c.f(c.lay.partials), fused_stats, c.f(c.lay.bpart), dgrad_border_waves(c.B, lh, lw, 16),
+    return launch_bn_bwd_finalize2(c.f(c.lay.partials), fused_stats, c.f(c.lay.bpart), border_rows >= 0 ? border_rows : dgrad_border_waves(c.B, lh, lw, 16),
                                    L.cout, (double)npix, c.scale(l), c.f(c.lay.mean) + L.ch_off,
                                    c.f(c.lay.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
                                    reinterpret_cast<double*>(c.f(c.lay.coef)), c.s, c.shift(l), c.params + L.beta_off, coef_f);
@@ -527,11 +536,14 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   static const int dec_low[3] = {L_D3C, L_U1B, L_U2B}, dec_skip[3] = {L_D2C, L_D1C, L_IN3};
   static const int dec_a[3] = {L_U1A, L_U2A, L_U3A}, dec_b[3] = {L_U1B, L_U2B, L_U3B};
   static const int uc[3] = {64, 32, 16};
+  // the upsample adjoint that completes g of a low-resolution layer also leaves that layer's BatchNorm-backward sums (one
+  // row per workgroup): up_rows > 0 tells the next bn_unit_bwd of that layer to skip its reduce pass
+  int up_rows = 0;
   for (int k = 2; k >= 0; --k) {
     const int lv = 2 - k;
     const int la = dec_a[k], lb = dec_b[k], ls = dec_skip[k], ll = dec_low[k];
     // second conv of the DoubleConvolution (k == 2: dy already produced by the fused tail above)
-    if (k != 2) SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), grads));
+    if (k != 2) SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), grads, nullptr, up_rows, 0));
     SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads, k == 2));
     int rows_a = 0;
     SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), nt.L[la].cout, nt.L[lb].cin, nullptr, 0, nullptr, la, &rows_a, k == 2));
@@ -539,7 +551,11 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), grads, nullptr, rows_a));
     SIFSR_TRY(conv_unit_wgrad(c, la, src_raw(c.f(w.U[k]), uc[k]), src_act(c, ls), c.f(w.g[la]), grads));
     SIFSR_TRY(conv_unit_dgrad(c, la, c.f(w.g[la]), c.f(w.gU[k]), uc[k], uc[k], c.f(w.g[ls]), nt.L[ls].cout, nullptr));
-    SIFSR_TRY(launch_up2x_bwd(c.f(w.gU[k]), c.f(w.g[ll]), B, c.lvH(lv + 1), c.lvW(lv + 1), uc[k], s));
+    up_rows = up2x_bwd_stat_rows(B, c.lvH(lv + 1), c.lvW(lv + 1), uc[k]);
+    if ((size_t)up_rows * uc[k] * 2 > w.partials_cap) up_rows = 0;
+    SIFSR_TRY(launch_up2x_bwd(c.f(w.gU[k]), c.f(w.g[ll]), B, c.lvH(lv + 1), c.lvW(lv + 1), uc[k], s,
+                              up_rows ? c.f(w.y[ll]) : nullptr, up_rows ? c.scale(ll) : nullptr, up_rows ? c.shift(ll) : nullptr,
+                              up_rows ? c.f(w.partials) : nullptr));
   }
 
   // encoder, last to first
@@ -551,7 +567,8 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     // lastconv: input R_k = P_k + relu(bn(y_b)); its gradient is both g(a_b) and part of g(P_k).
     // y_c also feeds the next pooling stage (k < 2): that AvgPool adjoint (of gP[k+1], computed in the previous
     // iteration) is folded into this BatchNorm backward instead of a separate accumulate pass over g[lc].
-    SIFSR_TRY(bn_unit_bwd(c, lc, c.f(w.g[lc]), grads, k < 2 ? c.f(w.gP[k + 1]) : nullptr));
+    // (k == 2: g of db3.lastconv came from the last upsample adjoint above, with its sums)
+    SIFSR_TRY(bn_unit_bwd(c, lc, c.f(w.g[lc]), grads, k < 2 ? c.f(w.gP[k + 1]) : nullptr, k == 2 ? up_rows : 0, 0));
     SIFSR_TRY(conv_unit_wgrad(c, lc, src_raw(c.f(w.R[k]), pc[k]), src_none(), c.f(w.g[lc]), grads));
     int rows_b = 0, rows_a = 0;
     SIFSR_TRY(conv_unit_dgrad(c, lc, c.f(w.g[lc]), c.f(w.g[lb]), pc[k], pc[k], nullptr, 0, nullptr, lb, &rows_b));

@@ -187,9 +187,16 @@ __global__ __launch_bounds__(256) void bnrelu_up2x_tile_kernel(const float* __re
 // Adjoint, separable through LDS: one workgroup = 8x8 low-res pixels x 16 channels; the 19x19 high-res pixels that
 // can reach them (rows 2i-2 .. 2i+2 per low-res row i) are read ONCE (the gather form above reads every high-res
 // pixel from ~4 threads), reduced horizontally, then vertically.  Deterministic (gather, fixed order).
+// bn_y != nullptr: g IS the complete gradient w.r.t. relu(bn(y)) of the low-resolution layer (ub1 / ub2 / ub3's input
+// comes from ONE producer), so the workgroup also leaves that layer's BatchNorm-backward sums of its 8x8 pixels --
+// (sum dz, sum dz*y) per channel, dz = g*[y*scale + shift > 0] -- in row (b, by, bx) of bn_partials ([rows][C][2]); the
+// separate reduce pass over (g, y) is not launched (bn_bwd_finalize2 takes these sums).
 template <int C>
 __global__ __launch_bounds__(256) void up2x_bwd_tile_kernel(const float* __restrict__ gu, float* __restrict__ g, int Hin,
-                                                            int Win) {
+                                                            int Win, const float* __restrict__ bn_y,
+                                                            const float* __restrict__ bn_scale,
+                                                            const float* __restrict__ bn_shift,
+                                                            float* __restrict__ bn_partials) {
   SIFSR_CHAIN_PRIO();
   constexpr int TL = 8, HR = 2 * TL + 3, NCH = C / 16;
   __shared__ float4 hi[HR * HR * 4];
@@ -246,7 +253,30 @@ __global__ __launch_bounds__(256) void up2x_bwd_tile_kernel(const float* __restr
       const float4 v = tmp[((2 * il_y + k) * TL + il_x) * 4 + q];
       acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
     }
-    if (iy < Hin && ix < Win) st4(g + ((size_t)(b * Hin + iy) * Win + ix) * C + ch0 + 4 * q, acc);
+    const bool in = iy < Hin && ix < Win;
+    if (in) st4(g + ((size_t)(b * Hin + iy) * Win + ix) * C + ch0 + 4 * q, acc);
+    if (bn_partials != nullptr) {
+      float4 d1 = make_float4(0.f, 0.f, 0.f, 0.f), d2 = d1;
+      if (in) {
+        const float4 yv = ld4(bn_y + ((size_t)(b * Hin + iy) * Win + ix) * C + ch0 + 4 * q);
+        const float4 sc = ld4(bn_scale + ch0 + 4 * q), sh = ld4(bn_shift + ch0 + 4 * q);
+        d1.x = fmaf(yv.x, sc.x, sh.x) > 0.f ? acc.x : 0.f; d2.x = d1.x * yv.x;
+        d1.y = fmaf(yv.y, sc.y, sh.y) > 0.f ? acc.y : 0.f; d2.y = d1.y * yv.y;
+        d1.z = fmaf(yv.z, sc.z, sh.z) > 0.f ? acc.z : 0.f; d2.z = d1.z * yv.z;
+        d1.w = fmaf(yv.w, sc.w, sh.w) > 0.f ? acc.w : 0.f; d2.w = d1.w * yv.w;
+      }
+      __syncthreads();                    // tmp[] / hi[] have been consumed by everybody
+      hi[2 * tid] = d1; hi[2 * tid + 1] = d2;
+      __syncthreads();
+      if (tid < 32) {                     // (quad qq, component r, which sum): 64 pixels in a fixed order
+        const int qq = tid & 3, r = (tid >> 2) & 3, which = tid >> 4;
+        const float* base = reinterpret_cast<const float*>(hi) + which * 4 + r;
+        float sum = 0.f;
+        for (int pp = 0; pp < 64; ++pp) sum += base[(size_t)(pp * 4 + qq) * 8];
+        const size_t row = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        bn_partials[(row * C + ch0 + 4 * qq + r) * 2 + which] = sum;
+      }
+    }
   }
 }
 
@@ -290,13 +320,20 @@ int launch_pool2_bwd(const float* gp, float* g, int B, int H, int W, int C, int 
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
-int launch_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, hipStream_t s) {
+int up2x_bwd_stat_rows(int B, int Hin, int Win, int C) {
+  if (!((C == 16 || C == 32 || C == 64) && (size_t)B * (C / 16) <= 65535)) return 0;
+  return B * ((Hin + 7) / 8) * ((Win + 7) / 8);
+}
+
+int launch_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, hipStream_t s, const float* bn_y,
+                    const float* bn_scale, const float* bn_shift, float* bn_partials) {
   if (C % 4) return SIFSR_ERR_SHAPE;
+  if (bn_partials != nullptr && (!bn_y || !bn_scale || !bn_shift || up2x_bwd_stat_rows(B, Hin, Win, C) == 0)) return SIFSR_ERR_ARG;
   if ((C == 16 || C == 32 || C == 64) && (size_t)B * (C / 16) <= 65535) {
     const dim3 grid((Win + 7) / 8, (Hin + 7) / 8, B * (C / 16));
-    if (C == 16) hipLaunchKernelGGL((up2x_bwd_tile_kernel<16>), grid, dim3(256), 0, s, gu, g, Hin, Win);
-    else if (C == 32) hipLaunchKernelGGL((up2x_bwd_tile_kernel<32>), grid, dim3(256), 0, s, gu, g, Hin, Win);
-    else hipLaunchKernelGGL((up2x_bwd_tile_kernel<64>), grid, dim3(256), 0, s, gu, g, Hin, Win);
+    if (C == 16) hipLaunchKernelGGL((up2x_bwd_tile_kernel<16>), grid, dim3(256), 0, s, gu, g, Hin, Win, bn_y, bn_scale, bn_shift, bn_partials);
+    else if (C == 32) hipLaunchKernelGGL((up2x_bwd_tile_kernel<32>), grid, dim3(256), 0, s, gu, g, Hin, Win, bn_y, bn_scale, bn_shift, bn_partials);
+    else hipLaunchKernelGGL((up2x_bwd_tile_kernel<64>), grid, dim3(256), 0, s, gu, g, Hin, Win, bn_y, bn_scale, bn_shift, bn_partials);
     SIFSR_LAUNCH_CHECK();
     return SIFSR_OK;
   }

@@ -305,6 +305,20 @@ def test_resample(L, C, hw):
     torch.cuda.synchronize()
     assert rel_err(nchw(u.cpu()), u_ref) < TOL
     assert rel_err(nchw(g.cpu()), ga2_ref) < TOL
+    # ... with the BatchNorm-backward sums of the low-resolution layer (sum dz, sum dz*y; dz = g*[y*scale+shift > 0])
+    rows = L.call("sifsr_up2x_bwd_stat_rows", B, H, W, C)
+    if rows:
+        part = torch.full((rows, C, 2), float("nan"), device="cuda")
+        g2 = torch.empty(B, H, W, C, device="cuda")
+        L.call("sifsr_up2x_bwd_bn_sums", dev(nhwc(gu)), g2, B, H, W, C, yd, dsc, dsh, part, S())
+        torch.cuda.synchronize()
+        assert torch.equal(g2, g)
+        dz = ga2_ref.double() * (yraw.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None] > 0)
+        ps = part.cpu().double().sum(0)
+        assert torch.allclose(ps[:, 0], dz.sum((0, 2, 3)), rtol=1e-4, atol=1e-4)
+        assert torch.allclose(ps[:, 1], (dz * yraw.double()).sum((0, 2, 3)), rtol=1e-4, atol=1e-4)
+    else:
+        assert C == 8
 
 
 @pytest.mark.parametrize("hw", [(256, 256), (64, 128), (40, 56), (100, 36), (12, 16), (37, 50)])
