@@ -131,6 +131,15 @@ SIFSR_API int sifsr_conv3x3_wgrad_fused(const float* src0, int C0, const float* 
                                         const float* src1, int C1, const float* scale1, const float* shift1,
                                         const float* g, const float* y, const float* coef_f, int cout, float* scratch,
                                         int nblk, float* dw, int B, int H, int W, void* stream);
+/* Winograd F(3x3, 2x2) form of the weight gradient (fp32, even H and W): 16 instead of 36 matrix-core products per 2x2
+ * output patch and channel pair; every lane transforms its own (patch, channel) operand in registers from channel-plane
+ * tiles in LDS.  y == coef_f == NULL: g is dL/dy itself; otherwise as sifsr_conv3x3_wgrad_fused.  Results differ from
+ * sifsr_conv3x3_wgrad by fp32 rounding only (slabs are reduced and transformed in float64). */
+SIFSR_API size_t sifsr_conv3x3_wgrad_wino_scratch_floats(int cin, int cout, int nblk);
+SIFSR_API int sifsr_conv3x3_wgrad_wino(const float* src0, int C0, const float* scale0, const float* shift0,
+                                       const float* src1, int C1, const float* scale1, const float* shift1,
+                                       const float* g, const float* y, const float* coef_f, int cout, float* scratch,
+                                       int nblk, float* dw, int B, int H, int W, void* stream);
 /* bf16-operand form of the weight gradient (BASELINE.json config 5): the staged x and dy are rounded to bf16 when
  * read from LDS and contracted 16 pixels at a time with v_mfma_f32_16x16x16_bf16; fp32 accumulation and slabs. */
 SIFSR_API int sifsr_conv3x3_wgrad_bf16(const float* src0, int C0, const float* scale0, const float* shift0,

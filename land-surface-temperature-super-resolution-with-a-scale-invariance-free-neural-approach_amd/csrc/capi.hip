@@ -253,6 +253,30 @@ int sifsr_conv3x3_wgrad_fused(const float* src0, int C0, const float* scale0, co
   return launch_wgrad_reduce(scratch, nblk, cin, cout, wgrad_nbi_chunk(a, cin), dw, S(stream));
 }
 
+// Winograd F(3x3, 2x2) form.  scratch = [nblk slabs of 16*cin*cout floats | 16*cin*cout doubles]
+size_t sifsr_conv3x3_wgrad_wino_scratch_floats(int cin, int cout, int nblk) { return (size_t)(nblk + 2) * 16 * cin * cout; }
+
+int sifsr_conv3x3_wgrad_wino(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
+                             const float* scale1, const float* shift1, const float* g, const float* y, const float* coef_f,
+                             int cout, float* scratch, int nblk, float* dw, int B, int H, int W, void* stream) {
+  if (!src0 || C0 % 16 || (src1 && C1 % 16)) return SIFSR_ERR_SHAPE;
+  if (!g || ((y != nullptr) != (coef_f != nullptr))) return SIFSR_ERR_ARG;
+  WgradArgs a;
+  a.src[0] = mk_src(src0, C0, scale0, shift0);
+  a.src[1] = mk_src(src1, C1, scale1, shift1);
+  a.dy = g; a.dy_y = y; a.dy_coef = coef_f; a.slabs = scratch; a.B = B; a.H = H; a.W = W;
+  a.NQ = a.src[0].nq + a.src[1].nq;
+  a.ntiles = B * ((H + 7) / 8) * ((W + 15) / 16);
+  const int cin = 16 * a.NQ;
+  if (nblk > a.ntiles) nblk = a.ntiles;
+  if (!conv3x3_wgrad_use_wino(a, cin, cout)) return SIFSR_ERR_SHAPE;
+  int rc = launch_conv3x3_wgrad_wino(a, cin, cout, nblk, S(stream));
+  if (rc) return rc;
+  WgradReduceJob j;
+  j.slab_off = 0; j.nblk = nblk; j.cin = cin; j.cout = cout; j.nbi_chunk = wgrad_nbi_chunk(a, cin); j.w_off = 0;
+  return launch_wgrad_wino_finish(scratch, &j, 1, reinterpret_cast<double*>(scratch + (size_t)nblk * 16 * cin * cout), dw, S(stream));
+}
+
 // bf16-operand form (config 5): x and dy rounded to bf16 when read from LDS, fp32 accumulation
 int sifsr_conv3x3_wgrad_bf16(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
                         const float* scale1, const float* shift1, const float* dy, int cout, float* scratch, int nblk,

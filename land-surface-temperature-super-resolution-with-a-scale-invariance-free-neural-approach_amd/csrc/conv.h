@@ -79,6 +79,12 @@ size_t wgrad_slab_floats(int cin, int cout);   // floats per block
 struct WgradReduceJob { size_t slab_off; int nblk, cin, cout, nbi_chunk, w_off; };
 int launch_wgrad_reduce_batched(const float* ws, const WgradReduceJob* jobs, int njobs, float* grads, hipStream_t s);
 
+// Winograd F(3x3, 2x2) form of the weight gradient (conv_wgrad_wino.hip): same arguments and grid as launch_conv3x3_wgrad,
+// slabs of 16 * cin * cout floats per block; the finish call reduces the slabs (float64) and applies the output transform.
+bool conv3x3_wgrad_use_wino(const WgradArgs& a, int cin, int cout);
+int launch_conv3x3_wgrad_wino(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s);
+int launch_wgrad_wino_finish(const float* ws, const WgradReduceJob* jobs, int njobs, double* mbuf, float* grads, hipStream_t s);
+
 // dgrad: replicate-padding adjoint fold for the border pixels (adds to g_in).  wdg_layer = the layer's
 // dgrad weight pack [fragment order | tap-major] written by pack_weights.
 int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, int Cin, float* g0, int C0,

@@ -1,0 +1,422 @@
+// Weight gradient of the replicate-padded 3x3 convolution in the Winograd F(3x3, 2x2) domain, fp32 matrix cores.
+//
+//   dW[co][ci][i][j] = sum over 2x2 output patches P of  sum_{a,b in {0,1}} d_P[i+a][j+b][ci] * g_P[a][b][co]
+// with d_P the 4x4 input window of the patch (replicate-clamped) and g_P the 2x2 patch of dL/dy -- the correlation of a
+// 4x4 tile with a 2x2 kernel giving 3x3 outputs, i.e. F(3x3, 2x2):
+//   dW = A^T [ sum_P (G g_P G^T) . (B^T d_P B) ] A,      16 products per patch and channel pair instead of 36
+//   B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,-1,0,1]],  G = [[1,0],[1,1],[1,-1],[0,1]],
+//   A^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]          (the halves of the textbook G moved into A^T: G stays exact)
+// (nn.Conv2d backward-weight, model.py:135,138,507.)
+//
+// GEMM view per transform-domain position xi = (u, v): M_xi (Cout x Cin) += Ug_xi^T (Cout x patches) * V_xi (patches x Cin),
+// v_mfma_f32_16x16x4_f32 with the 4-deep K index = 4 neighbouring patches of a patch row:
+//   A operand: lane (i = cout, k = patch)  needs ONE value per xi: Ug_xi of (patch k, channel i)
+//   B operand: lane (j = cin,  k = patch)  needs ONE value per xi: V_xi  of (patch k, channel j)
+// The transforms act per (patch, channel), so the lane that feeds the MFMA computes them itself, in registers, from the raw
+// tiles: LDS holds the dy tile and the input halo tile as CHANNEL PLANES [channel][pixel] (plane strides = 8 mod 64 dwords),
+// a lane reads its 2x2 patch (2 ds_read_b64) and its 4x4 window (8 ds_read_b64: two horizontally adjacent pixels of one
+// channel are one 8-byte word) without bank conflicts, transforms (row stage as v_pk_add_f32 on the pixel pairs, column
+// stage scalar: 34 vector instructions), and issues the 16 MFMAs of the k-step.  Nothing transform-domain ever goes through
+// LDS (an earlier form that staged Ug and V in LDS for the MFMAs to read was 2x slower than the tap-domain kernel: 64-96 KB
+// of LDS per workgroup, two barriers per 0.4 us of matrix work).  Same skeleton as conv_wgrad.hip otherwise: persistent
+// workgroups over 8x16-pixel tiles, the next tile's operands prefetched into registers, BatchNorm+ReLU of the producing
+// layer and the BatchNorm+ReLU backward of this layer (DYF, bn_bwd4) applied while staging, one slab per workgroup.
+// Slabs hold 16 transform-domain values per weight pair; wgrad_wino_reduce sums them in float64 (fixed order) and
+// wgrad_wino_finish applies A^T . A and scatters to the OIHW gradient.
+#include "conv.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int XT_ROWS = 8;                 // tile rows (4 patch rows x 8 patch columns = 32 patches = 8 k-steps)
+constexpr int XPW = 18, XPH = XT_ROWS + 2; // halo tile
+constexpr int XPIX_IN = XPW * XPH;         // 180
+constexpr int XPIX_OUT = 16 * XT_ROWS;     // 128
+constexpr int XPSO = 136, XPSI = 200;      // channel-plane strides in floats, = 8 (mod 64)
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4x;
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t xw_rsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+static __device__ __forceinline__ float4 xw_bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4x v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+template <int NBO, int NBI, bool DYF>   // cout blocks, cin blocks handled by one workgroup (cin chunk = blockIdx.y)
+__global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs a, const int lgx, const int lgy) {
+  constexpr int WO = NBO >= 2 ? 2 : 1, WI = NBI >= 2 ? 2 : 1, WP = 4 / (WO * WI);
+  constexpr int NBO_W = NBO / WO, NBI_W = NBI / WI;
+  constexpr int QO = NBO * 4, QI = NBI * 4;                   // channel quads per pixel (dy / input chunk)
+  constexpr int PPO = 256 / QO, PPI = 256 / QI;               // pixels staged per pass by the workgroup
+  constexpr int NIO = XPIX_OUT / PPO;                         // prefetch float4s per thread, dy tile
+  constexpr int NII = (XPIX_IN + PPI - 1) / PPI;              // ... input halo tile (last pass partial)
+  constexpr int KSW = 8 / WP;                                 // k-steps per wave per tile
+
+  __shared__ __align__(16) float smem[NBO * 16 * XPSO + NBI * 16 * XPSI];
+  float* const lds_dy = smem;
+  float* const lds_in = smem + NBO * 16 * XPSO;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wo = wave % WO, wi = (wave / WO) % WI, wp = wave / (WO * WI);
+  const int H = a.H, W = a.W;
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + XT_ROWS - 1) / XT_ROWS;   // last row / column of tiles may be partial
+  const int q0 = blockIdx.y * NBI;   // first 16-channel block of my cin chunk
+  constexpr int Cout = NBO * 16;
+  const unsigned npix = (unsigned)a.B * (unsigned)H * (unsigned)W;
+
+  // the cin chunk lies entirely in one of the two concatenated sources (chunks are <= 32 channels)
+  const bool first = q0 < a.src[0].nq;
+  const ConvSrc& src = first ? a.src[0] : a.src[1];
+  const int ch0 = src.coff + 16 * (first ? q0 : q0 - a.src[0].nq);
+  const int lgc = 31 - __builtin_clz((unsigned)src.C) + 2;                 // log2(C * 4 bytes)
+  const __amdgpu_buffer_rsrc_t rin = xw_rsrc(src.ptr, npix * (unsigned)src.C * 4u);
+  const __amdgpu_buffer_rsrc_t rdy = xw_rsrc(a.dy, npix * (unsigned)Cout * 4u);
+  const __amdgpu_buffer_rsrc_t rdyy = xw_rsrc(DYF ? a.dy_y : a.dy, npix * (unsigned)Cout * 4u);
+
+  // ---- per-thread staging constants (tile independent) ----
+  const int c4o = tid % QO, po0 = tid / QO;      // dy: pixel po0 + i*PPO, channels 4*c4o..
+  const int c4i = tid % QI, pi0 = tid / QI;      // input halo: pixel pi0 + i*PPI
+  unsigned vo_dy[NIO];
+#pragma unroll
+  for (int i = 0; i < NIO; ++i) {
+    const int p = po0 + i * PPO;
+    vo_dy[i] = (unsigned)(((p >> 4) * W + (p & 15)) * Cout * 4 + c4o * 16);
+  }
+  int ipy[NII], ipx[NII];
+#pragma unroll
+  for (int i = 0; i < NII; ++i) {
+    int p = pi0 + i * PPI;
+    if (p >= XPIX_IN) p = XPIX_IN - 1;
+    ipy[i] = p / XPW;
+    ipx[i] = p - ipy[i] * XPW;
+  }
+  float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool raw = src.scale == nullptr;
+  if (!raw) { psc = ld4(src.scale + ch0 + 4 * c4i); psh = ld4(src.shift + ch0 + 4 * c4i); }
+  float4 dsc = make_float4(0.f, 0.f, 0.f, 0.f), dsh = dsc, dk1 = dsc, dk0 = dsc;
+  if (DYF) {
+    dsc = ld4(a.dy_coef + 4 * c4o); dsh = ld4(a.dy_coef + Cout + 4 * c4o);
+    dk1 = ld4(a.dy_coef + 2 * Cout + 4 * c4o); dk0 = ld4(a.dy_coef + 3 * Cout + 4 * c4o);
+  }
+
+  f32x4 acc[NBO_W][NBI_W][16];
+#pragma unroll
+  for (int o = 0; o < NBO_W; ++o)
+#pragma unroll
+    for (int i = 0; i < NBI_W; ++i)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[o][i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 pdy[NIO], pin[NII], pyy[DYF ? NIO : 1];
+  auto issue = [&](int tile) {
+    int txi, tyi, b;
+    if (lgx >= 0) { txi = tile & (tiles_x - 1); tyi = (tile >> lgx) & (tiles_y - 1); b = tile >> (lgx + lgy); }
+    else { txi = tile % tiles_x; const int r = tile / tiles_x; tyi = r % tiles_y; b = r / tiles_y; }
+    const int x0 = txi * 16, y0 = tyi * XT_ROWS;
+    const unsigned base = (unsigned)((b * H + y0) * W + x0);
+    const bool full = x0 + 16 <= W && y0 + XT_ROWS <= H;
+#pragma unroll
+    for (int i = 0; i < NIO; ++i) {
+      const int p = po0 + i * PPO;
+      // partial tile: dy of the pixels outside the image must read as 0 (they contribute nothing to dW)
+      const bool in = full || (y0 + (p >> 4) < H && x0 + (p & 15) < W);
+      pdy[i] = xw_bload4(rdy, in ? vo_dy[i] : 0xFFFFFF00u, base * (unsigned)(Cout * 4));
+      if (DYF) pyy[i] = xw_bload4(rdyy, in ? vo_dy[i] : 0xFFFFFF00u, base * (unsigned)(Cout * 4));
+    }
+    const bool interior = txi > 0 && tyi > 0 && txi + 1 < tiles_x && tyi + 1 < tiles_y;
+    const unsigned chb = (unsigned)(ch0 + 4 * c4i) * 4u;
+    if (interior) {
+      const unsigned soff = ((base - (unsigned)W - 1u) << lgc);
+#pragma unroll
+      for (int i = 0; i < NII; ++i) pin[i] = xw_bload4(rin, ((unsigned)(ipy[i] * W + ipx[i]) << lgc) + chb, soff);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NII; ++i) {
+        const int gy = clampi(y0 - 1 + ipy[i], 0, H - 1), gx = clampi(x0 - 1 + ipx[i], 0, W - 1);
+        pin[i] = xw_bload4(rin, ((unsigned)((b * H + gy) * W + gx) << lgc) + chb, 0u);
+      }
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) issue(tile);
+  const int i16 = lane & 15, k = lane >> 4;
+  // my channel planes; my patch of k-step h: patch row h >> 1, patch column 4 * (h & 1) + k
+  const float* const pa = lds_dy + (16 * (wo * NBO_W) + i16) * XPSO + 2 * k;
+  const float* const pb = lds_in + (16 * (wi * NBI_W) + i16) * XPSI + 2 * k;
+
+  while (tile < a.ntiles) {
+    __syncthreads();          // previous tile's reads are done
+    {
+      int txi, tyi;
+      if (lgx >= 0) { txi = tile & (tiles_x - 1); tyi = (tile >> lgx) & (tiles_y - 1); }
+      else { txi = tile % tiles_x; tyi = (tile / tiles_x) % tiles_y; }
+      const int x0 = txi * 16, y0 = tyi * XT_ROWS;
+      const bool full = x0 + 16 <= W && y0 + XT_ROWS <= H;
+#pragma unroll
+      for (int i = 0; i < NIO; ++i) {
+        const int p = po0 + i * PPO;
+        float4 v = pdy[i];
+        if (DYF) {
+          v = bn_bwd4(v, pyy[i], dsc, dsh, dk1, dk0);
+          if (!full && !(y0 + (p >> 4) < H && x0 + (p & 15) < W)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float* d = lds_dy + (4 * c4o) * XPSO + p;
+        d[0] = v.x; d[XPSO] = v.y; d[2 * XPSO] = v.z; d[3 * XPSO] = v.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NII; ++i) {
+      const int p = pi0 + i * PPI;
+      float4 v = pin[i];
+      if (!raw) v = bn_relu4(v, psc, psh);
+      if (i + 1 < NII || p < XPIX_IN) {
+        float* d = lds_in + (4 * c4i) * XPSI + p;
+        d[0] = v.x; d[XPSI] = v.y; d[2 * XPSI] = v.z; d[3 * XPSI] = v.w;
+      }
+    }
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < a.ntiles) issue(next);     // in flight during the MFMA phase below
+
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+      const int h = wp + WP * j;                 // k-step: patch row h >> 1, patch columns 4 * (h & 1) + (0..3)
+      const int pr = h >> 1, pcb = 4 * (h & 1);
+      // ---- A side: Ug = G g G^T of my (patch, cout) for each of my cout blocks
+      float ug[NBO_W][16];
+#pragma unroll
+      for (int o = 0; o < NBO_W; ++o) {
+        const float* q = pa + (16 * o) * XPSO + (2 * pr) * 16 + 2 * pcb;
+        const f32x2 g0 = *reinterpret_cast<const f32x2*>(q), g1 = *reinterpret_cast<const f32x2*>(q + 16);
+        const f32x2 r1 = pk_add(g0, g1), r2 = pk_sub(g0, g1);                 // rows of G g: [g0, g0 + g1, g0 - g1, g1]
+        const f32x2 rows[4] = {g0, r1, r2, g1};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                                         // columns: (x, y) -> [x, x + y, x - y, y]
+          ug[o][4 * u + 0] = rows[u][0]; ug[o][4 * u + 1] = rows[u][0] + rows[u][1];
+          ug[o][4 * u + 2] = rows[u][0] - rows[u][1]; ug[o][4 * u + 3] = rows[u][1];
+        }
+      }
+      // ---- B side: V = B^T d B of my (patch, cin) for each of my cin blocks
+      float vv[NBI_W][16];
+#pragma unroll
+      for (int n = 0; n < NBI_W; ++n) {
+        const float* q = pb + (16 * n) * XPSI + (2 * pr) * XPW + 2 * pcb;
+        f32x2 dl[4], dh[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { dl[u] = *reinterpret_cast<const f32x2*>(q + u * XPW); dh[u] = *reinterpret_cast<const f32x2*>(q + u * XPW + 2); }
+        // rows: [d0 - d2, d1 + d2, d2 - d1, d3 - d1] on both pixel pairs
+        const f32x2 rl[4] = {pk_sub(dl[0], dl[2]), pk_add(dl[1], dl[2]), pk_sub(dl[2], dl[1]), pk_sub(dl[3], dl[1])};
+        const f32x2 rh[4] = {pk_sub(dh[0], dh[2]), pk_add(dh[1], dh[2]), pk_sub(dh[2], dh[1]), pk_sub(dh[3], dh[1])};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                                         // columns: same pattern on (x0, x1 | x2, x3)
+          vv[n][4 * u + 0] = rl[u][0] - rh[u][0]; vv[n][4 * u + 1] = rl[u][1] + rh[u][0];
+          vv[n][4 * u + 2] = rh[u][0] - rl[u][1]; vv[n][4 * u + 3] = rh[u][1] - rl[u][1];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int o = 0; o < NBO_W; ++o)
+#pragma unroll
+          for (int n = 0; n < NBI_W; ++n)
+            acc[o][n][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ug[o][t], vv[n][t], acc[o][n][t], 0, 0, 0);
+    }
+    tile = next;
+  }
+
+  // ---- combine the WP pixel-split waves through LDS, then write the slab ----
+  // slab layout (floats): [chunk][nbo][nbi][xi][lane][4]
+  constexpr int NT = NBO_W * NBI_W * 16;
+  const size_t slab_floats = (size_t)gridDim.y * NBO * NBI * 16 * 256;
+  float* slab = a.slabs + (size_t)blockIdx.x * slab_floats + (size_t)blockIdx.y * NBO * NBI * 16 * 256;
+  if (WP > 1) {
+    // the accumulators of one extra wave group do not all fit the tile buffers at once: park / add them 4 xi at a time
+    static_assert(WO * WI * NBO_W * NBI_W * 4 * 256 <= NBO * 16 * XPSO + NBI * 16 * XPSI, "wgrad reduction scratch too small");
+    float* const mine = smem + ((size_t)(wi * WO + wo) * NBO_W * NBI_W * 4) * 256;
+    for (int w = 1; w < WP; ++w) {
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq) {
+        __syncthreads();
+        if (wp == w) {
+#pragma unroll
+          for (int o = 0; o < NBO_W; ++o)
+#pragma unroll
+            for (int i = 0; i < NBI_W; ++i)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const f32x4 v = acc[o][i][4 * tq + t];
+                *reinterpret_cast<float4*>(mine + ((o * NBI_W + i) * 4 + t) * 256 + lane * 4) = make_float4(v[0], v[1], v[2], v[3]);
+              }
+        }
+        __syncthreads();
+        if (wp == 0) {
+#pragma unroll
+          for (int o = 0; o < NBO_W; ++o)
+#pragma unroll
+            for (int i = 0; i < NBI_W; ++i)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const float4 v = *reinterpret_cast<const float4*>(mine + ((o * NBI_W + i) * 4 + t) * 256 + lane * 4);
+                f32x4& r = acc[o][i][4 * tq + t];
+                r[0] += v.x; r[1] += v.y; r[2] += v.z; r[3] += v.w;
+              }
+        }
+      }
+    }
+  }
+  (void)NT;
+  if (wp == 0) {
+#pragma unroll
+    for (int o = 0; o < NBO_W; ++o)
+#pragma unroll
+      for (int i = 0; i < NBI_W; ++i)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int nbo = wo * NBO_W + o, nbi = wi * NBI_W + i;
+          const f32x4 v = acc[o][i][t];
+          st4(slab + ((size_t)((nbo * NBI + nbi) * 16 + t)) * 256 + lane * 4, make_float4(v[0], v[1], v[2], v[3]));
+        }
+  }
+}
+
+struct WinoReduceTable {
+  unsigned long long slab_off[16];
+  int nblk[16], cin[16], cout[16], nbi_chunk[16], w_off[16], blk_start[17];
+  int njobs;
+};
+
+// Sum of the slabs of every layer (float64, fixed order) -> mbuf, same element order as one slab:
+// block -> (layer, 32 consecutive slab elements = one 128-byte line per slab); 8 lanes x float4 cover the line, 32 lane
+// groups walk the slabs (conv_wgrad.hip: wgrad_reduce_batched_kernel, with 16 instead of 9 values per weight).
+__global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __restrict__ ws, const WinoReduceTable tb,
+                                                                double* __restrict__ mbuf) {
+  __shared__ double part[32][8][4];
+  int l = 0;
+  while (l + 1 < tb.njobs && (int)blockIdx.x >= tb.blk_start[l + 1]) ++l;
+  const int n = 16 * tb.cin[l] * tb.cout[l];
+  const int nblk = tb.nblk[l];
+  const float* slabs = ws + tb.slab_off[l];
+  const int jl = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int j4 = ((int)blockIdx.x - tb.blk_start[l]) * 32 + 4 * jl;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+  for (int kk = grp; kk < nblk; kk += 32) {
+    const float4 v = ld4(slabs + (size_t)kk * n + j4);
+    s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+  }
+  part[grp][jl][0] = s0; part[grp][jl][1] = s1; part[grp][jl][2] = s2; part[grp][jl][3] = s3;
+  __syncthreads();
+  for (int st = 16; st > 0; st >>= 1) {
+    if (grp < st) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[grp][jl][r] += part[grp + st][jl][r];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 32) mbuf[(size_t)blockIdx.x * 32 + threadIdx.x] = part[0][threadIdx.x >> 2][threadIdx.x & 3];
+}
+
+// dW = A^T M A per (cout, cin) pair, float64, scattered to the OIHW gradient.  One thread per pair.
+// mbuf element order: [chunk][nbo][nbi][xi][lane][r], co = 16 nbo + 4 (lane >> 4) + r, ci = 16 (chunk * nbi_chunk + nbi) + (lane & 15)
+__global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const double* __restrict__ mbuf, const WinoReduceTable tb,
+                                                                float* __restrict__ grads) {
+  const int l = blockIdx.y;
+  const int cin = tb.cin[l], cout = tb.cout[l], nbic = tb.nbi_chunk[l];
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= cin * cout) return;
+  const int co = e / cin, ci = e - co * cin;
+  const int nbo = co >> 4, r = co & 3, lk = (co >> 2) & 3;
+  const int qi = ci >> 4, chunk = qi / nbic, nbi = qi - chunk * nbic, li = ci & 15;
+  const int NBO = cout / 16;
+  const double* m = mbuf + (size_t)tb.blk_start[l] * 32 + ((size_t)((chunk * NBO + nbo) * nbic + nbi) * 16) * 256 + (lk * 16 + li) * 4 + r;
+  double M[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) M[u][v] = m[(size_t)(4 * u + v) * 256];
+  // t = A^T M (3 x 4), dW = t A (3 x 3);  A^T = [[1, .5, .5, 0], [0, .5, -.5, 0], [0, .5, .5, 1]]
+  double t[3][4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    t[0][v] = M[0][v] + 0.5 * (M[1][v] + M[2][v]);
+    t[1][v] = 0.5 * (M[1][v] - M[2][v]);
+    t[2][v] = 0.5 * (M[1][v] + M[2][v]) + M[3][v];
+  }
+  float* g = grads + tb.w_off[l] + (size_t)(co * cin + ci) * 9;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    g[3 * i + 0] = (float)(t[i][0] + 0.5 * (t[i][1] + t[i][2]));
+    g[3 * i + 1] = (float)(0.5 * (t[i][1] - t[i][2]));
+    g[3 * i + 2] = (float)(0.5 * (t[i][1] + t[i][2]) + t[i][3]);
+  }
+}
+
+template <int NBO, int NBI, bool DYF>
+int launch_xw(const WgradArgs& a, int chunks, int nblk, hipStream_t s) {
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+  const int tx_ = (a.W + 15) / 16, ty_ = (a.H + XT_ROWS - 1) / XT_ROWS;
+  const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
+  hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<NBO, NBI, DYF>), dim3(nblk, chunks), dim3(256), 0, s, a, lgx, lgy);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+}  // namespace
+
+bool conv3x3_wgrad_use_wino(const WgradArgs& a, int cin, int cout) {
+  static const int off = getenv("SIFSR_NO_WINO_WGRAD") ? atoi(getenv("SIFSR_NO_WINO_WGRAD")) : 0;   // 1: tap-domain weight gradients (A/B)
+  const int nbo = cout / 16, nbi = wgrad_nbi_chunk(a, cin);
+  const bool shape = (nbo == 1 || nbo == 2 || nbo == 4) && (nbi == 1 || nbi == 2) && !(nbo == 4 && nbi == 1);
+  return !off && a.bf16 == 0 && a.H % 2 == 0 && a.W % 2 == 0 && shape;
+}
+
+int launch_conv3x3_wgrad_wino(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s) {
+  if (a.H < 2 || a.W < 2 || cin % 16 || cout % 16 || nblk < 1) return SIFSR_ERR_SHAPE;
+  if (a.ntiles != a.B * ((a.H + XT_ROWS - 1) / XT_ROWS) * ((a.W + 15) / 16)) return SIFSR_ERR_ARG;
+  if (!conv3x3_wgrad_use_wino(a, cin, cout)) return SIFSR_ERR_SHAPE;
+  {
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    const size_t npix = (size_t)a.B * a.H * a.W;
+    int cmax = a.src[0].C > a.src[1].C ? a.src[0].C : a.src[1].C;
+    cmax = cmax > cout ? cmax : cout;
+    if (npix * cmax * 4 >= ((size_t)1 << 32) - 4096) return SIFSR_ERR_SHAPE;      // 32-bit buffer offsets
+    if (!pow2(a.src[0].C) || (a.src[1].ptr && !pow2(a.src[1].C))) return SIFSR_ERR_SHAPE;
+  }
+  const bool dyf = a.dy_y != nullptr;
+  if (dyf && !a.dy_coef) return SIFSR_ERR_ARG;
+  const int nbi = wgrad_nbi_chunk(a, cin), chunks = (cin / 16) / nbi, nbo = cout / 16;
+#define SIFSR_XW(NBOV, NBIV)                                                                                        \
+  if (nbo == NBOV && nbi == NBIV)                                                                                   \
+    return dyf ? launch_xw<NBOV, NBIV, true>(a, chunks, nblk, s) : launch_xw<NBOV, NBIV, false>(a, chunks, nblk, s);
+  SIFSR_XW(1, 1) SIFSR_XW(1, 2) SIFSR_XW(2, 1) SIFSR_XW(2, 2) SIFSR_XW(4, 2)
+#undef SIFSR_XW
+  return SIFSR_ERR_SHAPE;
+}
+
+// Slab reduction + output transform of a set of layers: two launches.  mbuf: >= sum over jobs of 16*cin*cout doubles.
+int launch_wgrad_wino_finish(const float* ws, const WgradReduceJob* jobs, int njobs, double* mbuf, float* grads, hipStream_t s) {
+  if (njobs < 1 || njobs > 16) return SIFSR_ERR_ARG;
+  WinoReduceTable tb;
+  int blk = 0, maxpairs = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const int n = 16 * jobs[i].cin * jobs[i].cout;
+    if (jobs[i].slab_off % 4) return SIFSR_ERR_SHAPE;
+    tb.slab_off[i] = jobs[i].slab_off; tb.nblk[i] = jobs[i].nblk; tb.cin[i] = jobs[i].cin; tb.cout[i] = jobs[i].cout;
+    tb.nbi_chunk[i] = jobs[i].nbi_chunk; tb.w_off[i] = jobs[i].w_off;
+    tb.blk_start[i] = blk;
+    blk += n / 32;
+    maxpairs = jobs[i].cin * jobs[i].cout > maxpairs ? jobs[i].cin * jobs[i].cout : maxpairs;
+  }
+  tb.blk_start[njobs] = blk;
+  tb.njobs = njobs;
+  hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(blk), dim3(256), 0, s, ws, tb, mbuf);
+  SIFSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((maxpairs + 255) / 256, njobs), dim3(256), 0, s, mbuf, tb, grads);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}

@@ -119,12 +119,16 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
     w.gU[0] = take(64 * N[2]); w.gU[1] = take(32 * N[1]); w.gU[2] = take(16 * N[0]);
     w.slabs = take(1024 * 288);   // edge-layer partials
     w.slab_l[0] = 0;
+    size_t wino_pairs = 0;
     for (int l = 1; l < SIFSR_NUM_BN_LAYERS; ++l) {
       const int lvh = H >> nt.L[l].level, lvw = W >> nt.L[l].level;
       const int ntiles = B * ((lvh + 7) / 8) * ((lvw + 15) / 16);
       // upper bound over chunkings (x-dim blocks * chunks <= blocks at one chunk)
-      w.slab_l[l] = take((size_t)wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles) * 9 * nt.L[l].cin * nt.L[l].cout);
+      // (16 values per weight pair: the Winograd F(3x3,2x2) form; the tap-domain form uses 9 of them)
+      w.slab_l[l] = take((size_t)wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles) * 16 * nt.L[l].cin * nt.L[l].cout);
+      wino_pairs += (size_t)nt.L[l].cin * nt.L[l].cout;
     }
+    w.wgm = take(2 * 16 * wino_pairs);
   }
   w.total = off;
   return SIFSR_OK;
@@ -144,6 +148,8 @@ struct Ctx {
   hipStream_t s;
   WgradReduceJob* jobs = nullptr;   // backward: slab reductions deferred to one batched launch
   int* njobs = nullptr;
+  WgradReduceJob* xjobs = nullptr;  // ... of the layers whose weight gradient ran in the Winograd domain
+  int* nxjobs = nullptr;
   int bf16 = 0;                     // 1: bf16 MFMA operands (config 5); 2: split-bf16 fp32 (conv forward / dgrad; wgrad stays fp32)
   struct SideLane* side = nullptr;  // backward: the weight gradients' own stream (nullptr = everything on s)
   bool* forked = nullptr;           // set once anything was enqueued on the side stream (SideLaneGuard)
@@ -338,6 +344,13 @@ int bn_unit_bwd(const Ctx& c, int l, float* g, float* grads, const float* gp = n
                                 reinterpret_cast<double*>(c.f(c.lay.coef)), c.s, c.shift(l), c.params + L.beta_off, coef_f);
 }
 
+static bool wgrad_wino_policy(int cin, int cout) {
+  // SIFSR_WGRAD_WINO: 0 = never, 1 = where measured faster (default), 2 = every layer
+  static const int mode = getenv("SIFSR_WGRAD_WINO") ? atoi(getenv("SIFSR_WGRAD_WINO")) : 1;
+  (void)cin;
+  return mode == 2 || (mode == 1 && cout <= 32);
+}
+
 // weight gradient of MFMA unit l from its forward inputs and dy
 // dy_stored: `dy` is dL/dy_l itself (ub3.convbloc.bloc.3, written by the fused tail); otherwise it is g_l and dL/dy_l is
 // formed while staging from (g_l, y_l, the coefficients bn_unit_bwd left)
@@ -360,12 +373,15 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
     ws = c.side->s;
     if (c.forked) *c.forked = true;
   }
+  // Winograd F(3x3,2x2) where it is the faster form (measured per shape, tools/sweep_layers.sh): up to 32 output channels
+  const bool wino = c.xjobs != nullptr && wgrad_wino_policy(L.cin, L.cout) && conv3x3_wgrad_use_wino(a, L.cin, L.cout);
   {
     ProfScope ps(l, 3, ws);
-    SIFSR_TRY(launch_conv3x3_wgrad(a, L.cin, L.cout, nblk, ws));
+    if (wino) SIFSR_TRY(launch_conv3x3_wgrad_wino(a, L.cin, L.cout, nblk, ws));
+    else SIFSR_TRY(launch_conv3x3_wgrad(a, L.cin, L.cout, nblk, ws));
   }
   if (c.jobs != nullptr) {
-    WgradReduceJob& j = c.jobs[(*c.njobs)++];
+    WgradReduceJob& j = wino ? c.xjobs[(*c.nxjobs)++] : c.jobs[(*c.njobs)++];
     j.slab_off = c.lay.slab_l[l]; j.nblk = nblk; j.cin = L.cin; j.cout = L.cout; j.nbi_chunk = nbi; j.w_off = L.w_off;
   } else {
     SIFSR_TRY(launch_wgrad_reduce(a.slabs, nblk, L.cin, L.cout, nbi, grads + L.w_off, c.s));
@@ -508,6 +524,14 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   WgradReduceJob jobs[16];
   int njobs = 0;
   c.jobs = jobs; c.njobs = &njobs;
+  WgradReduceJob xjobs[16];
+  int nxjobs = 0;
+  c.xjobs = xjobs; c.nxjobs = &nxjobs;
+  auto finish_wgrads = [&](hipStream_t st) -> int {
+    if (njobs > 0) SIFSR_TRY(launch_wgrad_reduce_batched(ws, jobs, njobs, grads, st));
+    if (nxjobs > 0) SIFSR_TRY(launch_wgrad_wino_finish(ws, xjobs, nxjobs, reinterpret_cast<double*>(c.f(w.wgm)), grads, st));
+    return SIFSR_OK;
+  };
   // tiny problems are launch-latency-bound: the 17 event hand-offs cost more than the overlap returns (batch 1 at 256x256:
   // 1.67 ms with the second stream, 1.56 without; batch 4: 1.72 against 1.81)
   c.side = (size_t)B * H * W >= 2u * 65536u || g_side_override == 1 ? side_lane(s) : nullptr;
@@ -589,7 +613,7 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   // that was the last MFMA layer: all 16 layers' weight-gradient slabs -> OIHW gradients, one launch.  With the second
   // stream it follows the last weight gradient there (it writes only the conv-weight regions of `grads`, which nothing
   // on the caller's stream touches) and overlaps the head of the chain instead of trailing it.
-  if (c.side != nullptr) SIFSR_TRY(launch_wgrad_reduce_batched(ws, jobs, njobs, grads, c.side->s));
+  if (c.side != nullptr) SIFSR_TRY(finish_wgrads(c.side->s));
   int rows_in0 = 0;
   SIFSR_TRY(conv_unit_dgrad(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), 16, 16, nullptr, 0, nullptr, L_IN0, &rows_in0));
   // first layer: no input gradient, so dy(L_IN0) is consumed by the weight gradient alone and is formed on the
@@ -618,7 +642,7 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   if (c.side != nullptr) {   // hand the second stream's work back to the caller's stream
     SIFSR_TRY(lane_guard.join());
   } else {
-    SIFSR_TRY(launch_wgrad_reduce_batched(ws, jobs, njobs, grads, s));
+    SIFSR_TRY(finish_wgrads(s));
   }
   return SIFSR_OK;
 }

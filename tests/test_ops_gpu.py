@@ -160,6 +160,12 @@ def test_conv3x3_fwd_dgrad_wgrad(L, case):
         L.call("sifsr_conv3x3_wgrad", d0, C0, dsc0, dsh0, d1, C1, dsc1, dsh1, ddy, cout, scratch, nb, dwo, B, H, W, S())
         torch.cuda.synchronize()
         assert rel_err(dwo.cpu(), gw_ref) < TOL, nb
+        if H % 2 == 0 and W % 2 == 0:                           # Winograd F(3x3, 2x2) form
+            scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_wino_scratch_floats", cin, cout, nb), device="cuda")
+            dwx = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+            L.call("sifsr_conv3x3_wgrad_wino", d0, C0, dsc0, dsh0, d1, C1, dsc1, dsh1, ddy, None, None, cout, scratch, nb, dwx, B, H, W, S())
+            torch.cuda.synchronize()
+            assert rel_err(dwx.cpu(), gw_ref) < TOL, nb
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 48), (1, 24, 40), (2, 40, 24)])   # full and partial 16x16 tiles
@@ -583,3 +589,9 @@ def test_bn_relu_backward_fused_into_dgrad_and_wgrad(L, case):
         L.call("sifsr_conv3x3_wgrad_fused", da, cin, None, None, None, 0, None, None, dg, y, coef_f, cout, scratch, nbk, dwo, B, H, W, S())
         torch.cuda.synchronize()
         assert rel_err(dwo.cpu(), gw_ref) < TOL, nbk
+        if H % 2 == 0 and W % 2 == 0:
+            scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_wino_scratch_floats", cin, cout, nbk), device="cuda")
+            dwx = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+            L.call("sifsr_conv3x3_wgrad_wino", da, cin, None, None, None, 0, None, None, dg, y, coef_f, cout, scratch, nbk, dwx, B, H, W, S())
+            torch.cuda.synchronize()
+            assert rel_err(dwx.cpu(), gw_ref) < TOL, nbk

@@ -1,5 +1,5 @@
 """Micro-benchmark of single conv ops through the C ABI (for PMC / tuning).
-usage: python tools/bench_conv.py [fwd|dgrad|wgrad] [cin] [cout] [H] [B] [iters]"""
+usage: python tools/bench_conv.py [fwd|dgrad|wgrad|wgradx] [cin] [cout] [H] [B] [iters]   (wgradx = Winograd F(3x3,2x2) weight gradient)"""
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sifsr
 from sifsr import _lib as L
@@ -27,6 +27,8 @@ g = torch.empty(B, H, H, cin, device=dev)
 nblk = int(os.environ.get("NBLK", 2048 if 9 * cin * cout <= 4608 else 1024))
 scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_scratch_floats", cin, cout, nblk), device=dev)
 dw = torch.empty_like(w)
+if op == "wgradx":
+    scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_wino_scratch_floats", cin, cout, nblk), device=dev)
 def run():
     if op == "fwd" and mode == "wino":
         L.call("sifsr_conv3x3_fwd_wino", x, cin, sc, sh, None, 0, None, None, wf, wwf, y, cout, part, B, H, H, S)
@@ -40,6 +42,8 @@ def run():
         L.call("sifsr_conv3x3_dgrad", dy, cout, wd, w, cin, g, cin, None, 0, None, B, H, H, S)
     elif op == "dgrad":
         L.call("sifsr_conv3x3_dgrad_" + mode, dy, cout, wd, cin, g, cin, None, 0, None, B, H, H, S)
+    elif op == "wgradx":
+        L.call("sifsr_conv3x3_wgrad_wino", x, cin, sc, sh, None, 0, None, None, dy, None, None, cout, scratch, nblk, dw, B, H, H, S)
     else:
         L.call("sifsr_conv3x3_wgrad", x, cin, sc, sh, None, 0, None, None, dy, cout, scratch, nblk, dw, B, H, H, S)
 for _ in range(3): run()
