@@ -13,7 +13,7 @@
 //   A operand: lane (i = cout, k = patch)  needs ONE value per xi: Ug_xi of (patch k, channel i)
 //   B operand: lane (j = cin,  k = patch)  needs ONE value per xi: V_xi  of (patch k, channel j)
 // The transforms act per (patch, channel), so the lane that feeds the MFMA computes them itself, in registers, from the raw
-// tiles: LDS holds the dy tile and the input halo tile as CHANNEL PLANES [channel][pixel] (plane strides = 8 mod 64 dwords),
+// tiles: LDS holds the dy tile and the input halo tile as CHANNEL PLANES [channel][pixel] (plane strides = 4 mod 64 dwords),
 // a lane reads its 2x2 patch (2 ds_read_b64) and its 4x4 window (8 ds_read_b64: two horizontally adjacent pixels of one
 // channel are one 8-byte word) without bank conflicts, transforms (row stage as v_pk_add_f32 on the pixel pairs, column
 // stage scalar: 34 vector instructions), and issues the 16 MFMAs of the k-step.  Nothing transform-domain ever goes through
@@ -33,7 +33,13 @@ constexpr int XT_ROWS = 8;                 // tile rows (4 patch rows x 8 patch 
 constexpr int XPW = 18, XPH = XT_ROWS + 2; // halo tile
 constexpr int XPIX_IN = XPW * XPH;         // 180
 constexpr int XPIX_OUT = 16 * XT_ROWS;     // 128
-constexpr int XPSO = 136, XPSI = 200;      // channel-plane strides in floats, = 8 (mod 64)
+// Channel planes in LDS: channel ch = 16 b + i lives at b * BS + slot(i) * PS with slot(i) = (i >> 2) + 4 * (i & 3).
+//   reads  (ds_read_b64, banks mod 64 per 32-lane half = 16 channels x 2 patches): PS = 4 (mod 64) -> 4 slot + 2 k + {0,1}: all 64 banks
+//   writes (ds_write_b32, banks mod 32 per 32-lane half = channel quads x consecutive pixels, one r = ch & 3 per instruction):
+//          16 b + 4 (quad & 3) + 16 r + pixel with BS = 16 (mod 32): conflict-free for 8 quads x 4 pixels, 2-way (free for a store) otherwise
+constexpr int XPSO = 132, XPSI = 196;
+constexpr int XBSO = 16 * XPSO + 16, XBSI = 16 * XPSI + 16;
+static __device__ __forceinline__ int xslot(int i) { return (i >> 2) + 4 * (i & 3); }
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4x;
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t xw_rsrc(const float* p, unsigned bytes) {
@@ -54,9 +60,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
   constexpr int NII = (XPIX_IN + PPI - 1) / PPI;              // ... input halo tile (last pass partial)
   constexpr int KSW = 8 / WP;                                 // k-steps per wave per tile
 
-  __shared__ __align__(16) float smem[NBO * 16 * XPSO + NBI * 16 * XPSI];
+  __shared__ __align__(16) float smem[NBO * XBSO + NBI * XBSI];
   float* const lds_dy = smem;
-  float* const lds_in = smem + NBO * 16 * XPSO;
+  float* const lds_in = smem + NBO * XBSO;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -145,8 +151,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
   if (tile < a.ntiles) issue(tile);
   const int i16 = lane & 15, k = lane >> 4;
   // my channel planes; my patch of k-step h: patch row h >> 1, patch column 4 * (h & 1) + k
-  const float* const pa = lds_dy + (16 * (wo * NBO_W) + i16) * XPSO + 2 * k;
-  const float* const pb = lds_in + (16 * (wi * NBI_W) + i16) * XPSI + 2 * k;
+  const float* const pa = lds_dy + (wo * NBO_W) * XBSO + xslot(i16) * XPSO + 2 * k;
+  const float* const pb = lds_in + (wi * NBI_W) * XBSI + xslot(i16) * XPSI + 2 * k;
 
   while (tile < a.ntiles) {
     __syncthreads();          // previous tile's reads are done
@@ -164,8 +170,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
           v = bn_bwd4(v, pyy[i], dsc, dsh, dk1, dk0);
           if (!full && !(y0 + (p >> 4) < H && x0 + (p & 15) < W)) v = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        float* d = lds_dy + (4 * c4o) * XPSO + p;
-        d[0] = v.x; d[XPSO] = v.y; d[2 * XPSO] = v.z; d[3 * XPSO] = v.w;
+        float* d = lds_dy + (c4o >> 2) * XBSO + (c4o & 3) * XPSO + p;      // channel 4 c4o + r -> slot (c4o & 3) + 4 r
+        d[0] = v.x; d[4 * XPSO] = v.y; d[8 * XPSO] = v.z; d[12 * XPSO] = v.w;
       }
     }
 #pragma unroll
@@ -174,8 +180,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
       float4 v = pin[i];
       if (!raw) v = bn_relu4(v, psc, psh);
       if (i + 1 < NII || p < XPIX_IN) {
-        float* d = lds_in + (4 * c4i) * XPSI + p;
-        d[0] = v.x; d[XPSI] = v.y; d[2 * XPSI] = v.z; d[3 * XPSI] = v.w;
+        float* d = lds_in + (c4i >> 2) * XBSI + (c4i & 3) * XPSI + p;
+        d[0] = v.x; d[4 * XPSI] = v.y; d[8 * XPSI] = v.z; d[12 * XPSI] = v.w;
       }
     }
     __syncthreads();
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
       float ug[NBO_W][16];
 #pragma unroll
       for (int o = 0; o < NBO_W; ++o) {
-        const float* q = pa + (16 * o) * XPSO + (2 * pr) * 16 + 2 * pcb;
+        const float* q = pa + o * XBSO + (2 * pr) * 16 + 2 * pcb;
         const f32x2 g0 = *reinterpret_cast<const f32x2*>(q), g1 = *reinterpret_cast<const f32x2*>(q + 16);
         const f32x2 r1 = pk_add(g0, g1), r2 = pk_sub(g0, g1);                 // rows of G g: [g0, g0 + g1, g0 - g1, g1]
         const f32x2 rows[4] = {g0, r1, r2, g1};
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
       float vv[NBI_W][16];
 #pragma unroll
       for (int n = 0; n < NBI_W; ++n) {
-        const float* q = pb + (16 * n) * XPSI + (2 * pr) * XPW + 2 * pcb;
+        const float* q = pb + n * XBSI + (2 * pr) * XPW + 2 * pcb;
         f32x2 dl[4], dh[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { dl[u] = *reinterpret_cast<const f32x2*>(q + u * XPW); dh[u] = *reinterpret_cast<const f32x2*>(q + u * XPW + 2); }
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
   float* slab = a.slabs + (size_t)blockIdx.x * slab_floats + (size_t)blockIdx.y * NBO * NBI * 16 * 256;
   if (WP > 1) {
     // the accumulators of one extra wave group do not all fit the tile buffers at once: park / add them 4 xi at a time
-    static_assert(WO * WI * NBO_W * NBI_W * 4 * 256 <= NBO * 16 * XPSO + NBI * 16 * XPSI, "wgrad reduction scratch too small");
+    static_assert(WO * WI * NBO_W * NBI_W * 4 * 256 <= NBO * XBSO + NBI * XBSI, "wgrad reduction scratch too small");
     float* const mine = smem + ((size_t)(wi * WO + wo) * NBO_W * NBI_W * 4) * 256;
     for (int w = 1; w < WP; ++w) {
 #pragma unroll

@@ -51,7 +51,7 @@ const NetTable& sifsr_net() {
 // ---------------------------------------------------------------------------------------------
 static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }   // in floats (256 B)
 
-static int wgrad_blocks(int cin, int cout, int chunks, int ntiles) {
+static int wgrad_blocks(int cin, int cout, int chunks, int ntiles, bool wino = false) {
   // persistent, software-pipelined workgroups: two per CU are resident (four for the 16->16 variant: 20 KB LDS,
   // 66 VGPRs), so launch that many in total (x-dim = total / Cin chunks in blockIdx.y), but keep >= 4 tiles per
   // workgroup so that the slab write + slab reduction stay small next to the MFMA work (measured per layer).
@@ -59,7 +59,12 @@ static int wgrad_blocks(int cin, int cout, int chunks, int ntiles) {
   // than they give -- 1024 / 512 stay)
   static const int dbg_scale = getenv("SIFSR_DBG_WGRAD_GRID_PCT") ? atoi(getenv("SIFSR_DBG_WGRAD_GRID_PCT")) : 100;   // tuning knob
   // (round 2, beside the Winograd chain -- one workgroup per CU, registers to spare: 1.5x the round-1 grids, +1 %; flat to 2.5x)
-  const int total = ((cin == 16 && cout == 16) ? 1536 : 768) * dbg_scale / 100;
+  // Winograd-domain kernels (conv_wgrad_wino.hip): two workgroups per CU are resident (registers), every workgroup walks the same
+  // number of tiles -> exactly one round of resident workgroups
+  static const int dbg_wino = getenv("SIFSR_DBG_WGRAD_WINO_GRID") ? atoi(getenv("SIFSR_DBG_WGRAD_WINO_GRID")) : 512;
+  static const int dbg_wino11 = getenv("SIFSR_DBG_WGRAD_WINO_GRID11") ? atoi(getenv("SIFSR_DBG_WGRAD_WINO_GRID11")) : 512;
+  const int wino_total = (cin == 16 && cout == 16) ? dbg_wino11 : dbg_wino;
+  const int total = wino ? (wino_total > 768 ? 768 : wino_total) : ((cin == 16 && cout == 16) ? 1536 : 768) * dbg_scale / 100;
   int n = total / chunks;
   if (n < 64) n = 64;
   const int cap = ntiles / 4 > 0 ? ntiles / 4 : 1;
@@ -345,8 +350,8 @@ int bn_unit_bwd(const Ctx& c, int l, float* g, float* grads, const float* gp = n
 }
 
 static bool wgrad_wino_policy(int cin, int cout) {
-  // SIFSR_WGRAD_WINO: 0 = never, 1 = where measured faster (default), 2 = every layer
-  static const int mode = getenv("SIFSR_WGRAD_WINO") ? atoi(getenv("SIFSR_WGRAD_WINO")) : 1;
+  // SIFSR_WGRAD_WINO: 0 = tap-domain kernels, 1 = Winograd up to 32 output channels, 2 = every layer (default; +5 % on the step)
+  static const int mode = getenv("SIFSR_WGRAD_WINO") ? atoi(getenv("SIFSR_WGRAD_WINO")) : 2;
   (void)cin;
   return mode == 2 || (mode == 1 && cout <= 32);
 }
@@ -365,7 +370,9 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
   a.ntiles = c.B * ((a.H + 7) / 8) * ((a.W + 15) / 16);
   a.bf16 = c.bf16 == 1 ? 1 : 0;   // the split-bf16 mode keeps the fp32 weight-gradient kernel
   const int nbi = wgrad_nbi_chunk(a, L.cin);
-  const int nblk = wgrad_blocks(L.cin, L.cout, L.cin / (16 * nbi), a.ntiles);
+  // Winograd F(3x3,2x2) where it is the faster form (measured per shape, tools/sweep_layers.sh)
+  const bool wino = c.xjobs != nullptr && wgrad_wino_policy(L.cin, L.cout) && conv3x3_wgrad_use_wino(a, L.cin, L.cout);
+  const int nblk = wgrad_blocks(L.cin, L.cout, L.cin / (16 * nbi), a.ntiles, wino);
   hipStream_t ws = c.s;
   if (c.side != nullptr && c.jobs != nullptr) {   // dy_l is complete on the main stream at this point
     if (hipEventRecord(c.side->ev[l], c.s) != hipSuccess || hipStreamWaitEvent(c.side->s, c.side->ev[l], 0) != hipSuccess)
@@ -373,8 +380,6 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
     ws = c.side->s;
     if (c.forked) *c.forked = true;
   }
-  // Winograd F(3x3,2x2) where it is the faster form (measured per shape, tools/sweep_layers.sh): up to 32 output channels
-  const bool wino = c.xjobs != nullptr && wgrad_wino_policy(L.cin, L.cout) && conv3x3_wgrad_use_wino(a, L.cin, L.cout);
   {
     ProfScope ps(l, 3, ws);
     if (wino) SIFSR_TRY(launch_conv3x3_wgrad_wino(a, L.cin, L.cout, nblk, ws));
