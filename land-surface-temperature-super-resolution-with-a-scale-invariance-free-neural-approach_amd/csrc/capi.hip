@@ -273,7 +273,7 @@ int sifsr_conv3x3_wgrad_wino(const float* src0, int C0, const float* scale0, con
   int rc = launch_conv3x3_wgrad_wino(a, cin, cout, nblk, S(stream));
   if (rc) return rc;
   WgradReduceJob j;
-  j.slab_off = 0; j.nblk = nblk; j.cin = cin; j.cout = cout; j.nbi_chunk = wgrad_nbi_chunk(a, cin); j.w_off = 0;
+  j.slab_off = 0; j.nblk = nblk; j.cin = cin; j.cout = cout; j.nbi_chunk = wgrad_wino_nbi_chunk(a, cin); j.w_off = 0;
   return launch_wgrad_wino_finish(scratch, &j, 1, reinterpret_cast<double*>(scratch + (size_t)nblk * 16 * cin * cout), dw, S(stream));
 }
 

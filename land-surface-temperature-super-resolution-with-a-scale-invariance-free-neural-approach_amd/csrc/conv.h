@@ -82,6 +82,7 @@ int launch_wgrad_reduce_batched(const float* ws, const WgradReduceJob* jobs, int
 // Winograd F(3x3, 2x2) form of the weight gradient (conv_wgrad_wino.hip): same arguments and grid as launch_conv3x3_wgrad,
 // slabs of 16 * cin * cout floats per block; the finish call reduces the slabs (float64) and applies the output transform.
 bool conv3x3_wgrad_use_wino(const WgradArgs& a, int cin, int cout);
+int wgrad_wino_nbi_chunk(const WgradArgs& a, int cin);   // its Cin chunking (a 32-channel chunk may span the two sources)
 int launch_conv3x3_wgrad_wino(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s);
 int launch_wgrad_wino_finish(const float* ws, const WgradReduceJob* jobs, int njobs, double* mbuf, float* grads, hipStream_t s);
 

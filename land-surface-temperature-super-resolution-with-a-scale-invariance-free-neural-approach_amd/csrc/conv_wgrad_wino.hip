@@ -73,10 +73,14 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
   constexpr int Cout = NBO * 16;
   const unsigned npix = (unsigned)a.B * (unsigned)H * (unsigned)W;
 
-  // the cin chunk lies entirely in one of the two concatenated sources (chunks are <= 32 channels)
-  const bool first = q0 < a.src[0].nq;
+  // A cin chunk normally lies in one of the two concatenated sources.  A 32-channel chunk that straddles them (an odd number
+  // of 16-channel blocks in the first source: ub3.convbloc.bloc.0 = cat(16, 16)) is staged with its two blocks on alternate
+  // waves, so that the source (a buffer resource, wave-uniform) is per wave: dy / (g, y) are then read once, not per block.
+  const bool straddle = NBI == 2 && a.src[1].ptr != nullptr && q0 < a.src[0].nq && q0 + NBI > a.src[0].nq;
+  const int qb = q0 + (straddle ? (wave & 1) : 0);          // the 16-channel block this wave stages from (first one if not straddling)
+  const bool first = qb < a.src[0].nq;
   const ConvSrc& src = first ? a.src[0] : a.src[1];
-  const int ch0 = src.coff + 16 * (first ? q0 : q0 - a.src[0].nq);
+  const int ch0 = src.coff + 16 * (first ? qb : qb - a.src[0].nq);
   const int lgc = 31 - __builtin_clz((unsigned)src.C) + 2;                 // log2(C * 4 bytes)
   const __amdgpu_buffer_rsrc_t rin = xw_rsrc(src.ptr, npix * (unsigned)src.C * 4u);
   const __amdgpu_buffer_rsrc_t rdy = xw_rsrc(a.dy, npix * (unsigned)Cout * 4u);
@@ -84,7 +88,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
 
   // ---- per-thread staging constants (tile independent) ----
   const int c4o = tid % QO, po0 = tid / QO;      // dy: pixel po0 + i*PPO, channels 4*c4o..
-  const int c4i = tid % QI, pi0 = tid / QI;      // input halo: pixel pi0 + i*PPI
+  // input halo: pixel pi0 + i*PPI, LDS channels 4*c4i.., source channels ch0 + 4*c4s..
+  const int c4i = straddle ? (tid & 3) + 4 * (wave & 1) : tid % QI;
+  const int pi0 = straddle ? ((tid >> 2) & 15) + 16 * (tid >> 7) : tid / QI;
+  const int c4s = straddle ? (tid & 3) : c4i;
   unsigned vo_dy[NIO];
 #pragma unroll
   for (int i = 0; i < NIO; ++i) {
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
   }
   float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool raw = src.scale == nullptr;
-  if (!raw) { psc = ld4(src.scale + ch0 + 4 * c4i); psh = ld4(src.shift + ch0 + 4 * c4i); }
+  if (!raw) { psc = ld4(src.scale + ch0 + 4 * c4s); psh = ld4(src.shift + ch0 + 4 * c4s); }
   float4 dsc = make_float4(0.f, 0.f, 0.f, 0.f), dsh = dsc, dk1 = dsc, dk0 = dsc;
   if (DYF) {
     dsc = ld4(a.dy_coef + 4 * c4o); dsh = ld4(a.dy_coef + Cout + 4 * c4o);
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
       if (DYF) pyy[i] = xw_bload4(rdyy, in ? vo_dy[i] : 0xFFFFFF00u, base * (unsigned)(Cout * 4));
     }
     const bool interior = txi > 0 && tyi > 0 && txi + 1 < tiles_x && tyi + 1 < tiles_y;
-    const unsigned chb = (unsigned)(ch0 + 4 * c4i) * 4u;
+    const unsigned chb = (unsigned)(ch0 + 4 * c4s) * 4u;
     if (interior) {
       const unsigned soff = ((base - (unsigned)W - 1u) << lgc);
 #pragma unroll
@@ -374,9 +381,15 @@ int launch_xw(const WgradArgs& a, int chunks, int nblk, hipStream_t s) {
 
 }  // namespace
 
+// 16-channel blocks per cin chunk (blockIdx.y): 32-channel chunks from 32 input channels on, also across the two sources
+int wgrad_wino_nbi_chunk(const WgradArgs& a, int cin) {
+  (void)a;
+  return cin < 32 ? 1 : 2;
+}
+
 bool conv3x3_wgrad_use_wino(const WgradArgs& a, int cin, int cout) {
   static const int off = getenv("SIFSR_NO_WINO_WGRAD") ? atoi(getenv("SIFSR_NO_WINO_WGRAD")) : 0;   // 1: tap-domain weight gradients (A/B)
-  const int nbo = cout / 16, nbi = wgrad_nbi_chunk(a, cin);
+  const int nbo = cout / 16, nbi = wgrad_wino_nbi_chunk(a, cin);
   const bool shape = (nbo == 1 || nbo == 2 || nbo == 4) && (nbi == 1 || nbi == 2) && !(nbo == 4 && nbi == 1);
   return !off && a.bf16 == 0 && a.H % 2 == 0 && a.W % 2 == 0 && shape;
 }
@@ -395,7 +408,7 @@ int launch_conv3x3_wgrad_wino(const WgradArgs& a, int cin, int cout, int nblk, h
   }
   const bool dyf = a.dy_y != nullptr;
   if (dyf && !a.dy_coef) return SIFSR_ERR_ARG;
-  const int nbi = wgrad_nbi_chunk(a, cin), chunks = (cin / 16) / nbi, nbo = cout / 16;
+  const int nbi = wgrad_wino_nbi_chunk(a, cin), chunks = (cin / 16) / nbi, nbo = cout / 16;
 #define SIFSR_XW(NBOV, NBIV)                                                                                        \
   if (nbo == NBOV && nbi == NBIV)                                                                                   \
     return dyf ? launch_xw<NBOV, NBIV, true>(a, chunks, nblk, s) : launch_xw<NBOV, NBIV, false>(a, chunks, nblk, s);

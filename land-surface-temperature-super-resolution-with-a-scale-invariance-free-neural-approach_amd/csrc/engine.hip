@@ -63,7 +63,8 @@ static int wgrad_blocks(int cin, int cout, int chunks, int ntiles, bool wino = f
   // number of tiles -> exactly one round of resident workgroups
   static const int dbg_wino = getenv("SIFSR_DBG_WGRAD_WINO_GRID") ? atoi(getenv("SIFSR_DBG_WGRAD_WINO_GRID")) : 512;
   static const int dbg_wino11 = getenv("SIFSR_DBG_WGRAD_WINO_GRID11") ? atoi(getenv("SIFSR_DBG_WGRAD_WINO_GRID11")) : 512;
-  const int wino_total = (cin == 16 && cout == 16) ? dbg_wino11 : dbg_wino;
+  static const int dbg_wino42 = getenv("SIFSR_DBG_WGRAD_WINO_GRID42") ? atoi(getenv("SIFSR_DBG_WGRAD_WINO_GRID42")) : 256;   // 64 output channels: one resident workgroup per CU
+  const int wino_total = (cin == 16 && cout == 16) ? dbg_wino11 : cout == 64 ? dbg_wino42 : dbg_wino;
   const int total = wino ? (wino_total > 768 ? 768 : wino_total) : ((cin == 16 && cout == 16) ? 1536 : 768) * dbg_scale / 100;
   int n = total / chunks;
   if (n < 64) n = 64;
@@ -369,9 +370,9 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
   a.NQ = L.cin / 16;
   a.ntiles = c.B * ((a.H + 7) / 8) * ((a.W + 15) / 16);
   a.bf16 = c.bf16 == 1 ? 1 : 0;   // the split-bf16 mode keeps the fp32 weight-gradient kernel
-  const int nbi = wgrad_nbi_chunk(a, L.cin);
   // Winograd F(3x3,2x2) where it is the faster form (measured per shape, tools/sweep_layers.sh)
   const bool wino = c.xjobs != nullptr && wgrad_wino_policy(L.cin, L.cout) && conv3x3_wgrad_use_wino(a, L.cin, L.cout);
+  const int nbi = wino ? wgrad_wino_nbi_chunk(a, L.cin) : wgrad_nbi_chunk(a, L.cin);
   const int nblk = wgrad_blocks(L.cin, L.cout, L.cin / (16 * nbi), a.ntiles, wino);
   hipStream_t ws = c.s;
   if (c.side != nullptr && c.jobs != nullptr) {   // dy_l is complete on the main stream at this point

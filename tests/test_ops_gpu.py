@@ -63,6 +63,7 @@ CONV_CASES = [
     (32, 0, 32, 24, 40, 2, True, False),
     (16, 0, 32, 20, 36, 1, True, False),
     (64, 0, 64, 4, 6, 2, True, False),
+    (16, 16, 16, 12, 20, 2, True, True),     # a 32-channel Cin chunk across the two sources, partial tiles
 ]
 
 
