@@ -57,13 +57,14 @@ F16 = 2 * 9 * 16 * 16 * 256 * 256
 ROOFLINE_KERNELS = {
     "fwd_16x16_256": (1, 1, F16, "conv3x3_mfma_kernel<1, false"),      # inbloc.bloc.3 forward
     "dgrad_16x16_256": (1, 2, F16, "conv3x3_mfma_kernel<1, true"),     # inbloc.bloc.3 input gradient (+ fused BN sums of inbloc.bloc.0)
-    "wgrad_16x16_256": (1, 3, F16, "conv3x3_wgrad_kernel<1, 1"),       # inbloc.bloc.3 weight gradient
+    "wgrad_16x16_256": (1, 3, F16, "conv3x3_wgrad_wino_kernel<1, 1, true"),   # inbloc.bloc.3 weight gradient
     "fwd_32x16_256": (15, 1, 2 * F16, "conv3x3_mfma_kernel<1, false"),  # ub3.convbloc.bloc.0 forward
-    "wgrad_32x16_256": (15, 3, 2 * F16, "conv3x3_wgrad_kernel<1, 1"),
+    "wgrad_32x16_256": (15, 3, 2 * F16, "conv3x3_wgrad_wino_kernel<1, 2"),
     "dgrad_32x16_256": (15, 2, 2 * F16, "conv3x3_mfma_kernel<2, true"),
 }
 SIDE_BY_SIDE = ("fwd_16x16_256", "dgrad_16x16_256", "wgrad_16x16_256")
-WINOGRAD = {"fwd_16x16_256", "dgrad_16x16_256", "fwd_32x16_256", "dgrad_32x16_256"}
+WINOGRAD = {"fwd_16x16_256", "dgrad_16x16_256", "fwd_32x16_256", "dgrad_32x16_256"}      # F(2x2,3x3)
+WINOGRAD_W = {"wgrad_16x16_256", "wgrad_32x16_256"}                                        # F(3x3,2x2)
 
 
 def dominant_kernel():
@@ -315,7 +316,8 @@ def main():
                               "solo_ms": round(solo, 4), "solo_frac": round(tf_solo / PEAK_FP32_MFMA_TFLOPS, 4),
                               "concurrent": "runs on the second stream beside the input-gradient chain" if name.startswith("wgrad") else
                                             ("shares the machine with the previous layer's weight gradient" if name.startswith("dgrad") else "alone"),
-                              "algorithm": "winograd F(2x2,3x3): 4/9 of the algorithmic MACs executed" if name in WINOGRAD else "direct"}
+                              "algorithm": "winograd F(2x2,3x3): 4/9 of the algorithmic MACs executed" if name in WINOGRAD else
+                                           ("winograd F(3x3,2x2): 4/9 of the algorithmic MACs executed" if name in WINOGRAD_W else "direct")}
             traffic, traffic_src = measured_traffic(dom)
             k = kern[dom]
             out_json["roofline"] = {

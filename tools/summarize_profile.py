@@ -67,7 +67,7 @@ for name, pattern, nth, per_step in [
         ("fwd_16x16_256", "conv3x3_mfma_kernel<1, false,", 0, 6),     # inbloc.bloc.3: first <1,false> launch of a step
         ("fwd_32x16_256", "conv3x3_mfma_kernel<1, false,", 4, 6),     # ub3.convbloc.bloc.0
         ("dgrad_16x16_256", "conv3x3_mfma_kernel<1, true,", 4, 5),    # inbloc.bloc.3: last 16-channel dgrad of the backward
-        ("wgrad_16x16_256", "conv3x3_wgrad_kernel<1, 1,", 4, 5)]:     # inbloc.bloc.3
+        ("wgrad_16x16_256", "conv3x3_wgrad_wino_kernel<1, 1, true>", 2, 3)]:     # inbloc.bloc.3 (after the two 128^2 layers)
     fr, wr = per_launch("fetch", pattern, nth, per_step), per_launch("write", pattern, nth, per_step)
     if fr is not None and wr is not None:
         traffic[name] = {"read_bytes": 2 * fr * 1024, "write_bytes": wr * 1024, "bytes": 2 * fr * 1024 + wr * 1024}
@@ -76,7 +76,7 @@ trace = glob.glob(f"{src}/stats/*/*kernel_trace.csv")
 if trace:
     trows = sorted(csv.DictReader(open(trace[0])), key=lambda r: int(r["Start_Timestamp"]))
     for name, pattern, nth, per_step in [("fwd_16x16_256", "conv3x3_mfma_kernel<1, false,", 0, 6), ("fwd_32x16_256", "conv3x3_mfma_kernel<1, false,", 4, 6),
-                                         ("dgrad_16x16_256", "conv3x3_mfma_kernel<1, true,", 4, 5), ("wgrad_16x16_256", "conv3x3_wgrad_kernel<1, 1,", 4, 5)]:
+                                         ("dgrad_16x16_256", "conv3x3_mfma_kernel<1, true,", 4, 5), ("wgrad_16x16_256", "conv3x3_wgrad_wino_kernel<1, 1, true>", 2, 3)]:
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trows if pattern in r["Kernel_Name"]]
         if len(d) >= per_step * steps and name in traffic:
             pick = d[nth::per_step][:steps]
@@ -95,7 +95,7 @@ cats = collections.OrderedDict([
     ("conv dgrad (MFMA)", lambda k: "conv3x3_mfma_kernel<" in k and k.split("conv3x3_mfma_kernel<")[1].split(",")[1].strip().startswith("true")),
     ("dgrad border", lambda k: "dgrad_border" in k),
     ("conv wgrad (MFMA)", lambda k: "conv3x3_wgrad" in k),
-    ("wgrad slab reduce", lambda k: "wgrad_reduce" in k),
+    ("wgrad slab reduce", lambda k: "wgrad_reduce" in k or "wgrad_wino_reduce" in k or "wgrad_wino_finish" in k),
     ("fused tail (outlay bwd + BN bwd)", lambda k: "tail_bwd" in k),
     ("BatchNorm backward", lambda k: "bn_bwd" in k),
     ("BatchNorm finalize / eval", lambda k: "bn_finalize" in k or "bn_eval" in k or "nbt_" in k),
