@@ -51,7 +51,10 @@ static __device__ __forceinline__ float4 xw_bload4(__amdgpu_buffer_rsrc_t r, uns
 }
 
 template <int NBO, int NBI, bool DYF>   // cout blocks, cin blocks handled by one workgroup (cin chunk = blockIdx.y)
-__global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs a, const int lgx, const int lgy) {
+__global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs a, const int lgx, const int lgy, const int Cout) {
+  // Cout = all output channels of the layer; this workgroup takes the NBO 16-channel blocks from block blockIdx.z * NBO on
+  // (64 output channels run as two halves of 32: the 32-channel variant keeps two workgroups per CU resident, the 64-channel
+  // one -- 436 registers -- only one)
   constexpr int WO = NBO >= 2 ? 2 : 1, WI = NBI >= 2 ? 2 : 1, WP = 4 / (WO * WI);
   constexpr int NBO_W = NBO / WO, NBI_W = NBI / WI;
   constexpr int QO = NBO * 4, QI = NBI * 4;                   // channel quads per pixel (dy / input chunk)
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
   const int H = a.H, W = a.W;
   const int tiles_x = (W + 15) / 16, tiles_y = (H + XT_ROWS - 1) / XT_ROWS;   // last row / column of tiles may be partial
   const int q0 = blockIdx.y * NBI;   // first 16-channel block of my cin chunk
-  constexpr int Cout = NBO * 16;
+  const int co0 = blockIdx.z * NBO * 16;      // my first output channel
   const unsigned npix = (unsigned)a.B * (unsigned)H * (unsigned)W;
 
   // A cin chunk normally lies in one of the two concatenated sources.  A 32-channel chunk that straddles them (an odd number
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
 #pragma unroll
   for (int i = 0; i < NIO; ++i) {
     const int p = po0 + i * PPO;
-    vo_dy[i] = (unsigned)(((p >> 4) * W + (p & 15)) * Cout * 4 + c4o * 16);
+    vo_dy[i] = (unsigned)(((p >> 4) * W + (p & 15)) * Cout * 4 + co0 * 4 + c4o * 16);
   }
   int ipy[NII], ipx[NII];
 #pragma unroll
@@ -111,8 +114,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
   if (!raw) { psc = ld4(src.scale + ch0 + 4 * c4s); psh = ld4(src.shift + ch0 + 4 * c4s); }
   float4 dsc = make_float4(0.f, 0.f, 0.f, 0.f), dsh = dsc, dk1 = dsc, dk0 = dsc;
   if (DYF) {
-    dsc = ld4(a.dy_coef + 4 * c4o); dsh = ld4(a.dy_coef + Cout + 4 * c4o);
-    dk1 = ld4(a.dy_coef + 2 * Cout + 4 * c4o); dk0 = ld4(a.dy_coef + 3 * Cout + 4 * c4o);
+    const float* cf = a.dy_coef + co0 + 4 * c4o;
+    dsc = ld4(cf); dsh = ld4(cf + Cout);
+    dk1 = ld4(cf + 2 * Cout); dk0 = ld4(cf + 3 * Cout);
   }
 
   f32x4 acc[NBO_W][NBI_W][16];
@@ -244,8 +248,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
   // ---- combine the WP pixel-split waves through LDS, then write the slab ----
   // slab layout (floats): [chunk][nbo][nbi][xi][lane][4]
   constexpr int NT = NBO_W * NBI_W * 16;
-  const size_t slab_floats = (size_t)gridDim.y * NBO * NBI * 16 * 256;
-  float* slab = a.slabs + (size_t)blockIdx.x * slab_floats + (size_t)blockIdx.y * NBO * NBI * 16 * 256;
+  const size_t slab_floats = (size_t)gridDim.y * gridDim.z * NBO * NBI * 16 * 256;   // = 16 * Cin * Cout
+  float* slab = a.slabs + (size_t)blockIdx.x * slab_floats + (size_t)(blockIdx.y * gridDim.z + blockIdx.z) * NBO * NBI * 16 * 256;
   if (WP > 1) {
     // the accumulators of one extra wave group do not all fit the tile buffers at once: park / add them 4 xi at a time
     static_assert(WO * WI * NBO_W * NBI_W * 4 * 256 <= NBO * XBSO + NBI * XBSI, "wgrad reduction scratch too small");
@@ -369,12 +373,12 @@ __global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const double* __
 }
 
 template <int NBO, int NBI, bool DYF>
-int launch_xw(const WgradArgs& a, int chunks, int nblk, hipStream_t s) {
+int launch_xw(const WgradArgs& a, int chunks, int halves, int nblk, hipStream_t s) {
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
   auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
   const int tx_ = (a.W + 15) / 16, ty_ = (a.H + XT_ROWS - 1) / XT_ROWS;
   const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
-  hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<NBO, NBI, DYF>), dim3(nblk, chunks), dim3(256), 0, s, a, lgx, lgy);
+  hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<NBO, NBI, DYF>), dim3(nblk, chunks, halves), dim3(256), 0, s, a, lgx, lgy, NBO * 16 * halves);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
@@ -409,10 +413,13 @@ int launch_conv3x3_wgrad_wino(const WgradArgs& a, int cin, int cout, int nblk, h
   const bool dyf = a.dy_y != nullptr;
   if (dyf && !a.dy_coef) return SIFSR_ERR_ARG;
   const int nbi = wgrad_wino_nbi_chunk(a, cin), chunks = (cin / 16) / nbi, nbo = cout / 16;
-#define SIFSR_XW(NBOV, NBIV)                                                                                        \
-  if (nbo == NBOV && nbi == NBIV)                                                                                   \
-    return dyf ? launch_xw<NBOV, NBIV, true>(a, chunks, nblk, s) : launch_xw<NBOV, NBIV, false>(a, chunks, nblk, s);
-  SIFSR_XW(1, 1) SIFSR_XW(1, 2) SIFSR_XW(2, 1) SIFSR_XW(2, 2) SIFSR_XW(4, 2)
+  static const int split64 = getenv("SIFSR_DBG_WGRAD_WINO_SPLIT64") ? atoi(getenv("SIFSR_DBG_WGRAD_WINO_SPLIT64")) : 1;   // A/B knob
+#define SIFSR_XW(NBOV, NBIV, HV)                                                                                     \
+  if (nbo == NBOV * HV && nbi == NBIV)                                                                              \
+    return dyf ? launch_xw<NBOV, NBIV, true>(a, chunks, HV, nblk, s) : launch_xw<NBOV, NBIV, false>(a, chunks, HV, nblk, s);
+  SIFSR_XW(1, 1, 1) SIFSR_XW(1, 2, 1) SIFSR_XW(2, 1, 1) SIFSR_XW(2, 2, 1)
+  if (split64) { SIFSR_XW(2, 2, 2) }
+  SIFSR_XW(4, 2, 1)
 #undef SIFSR_XW
   return SIFSR_ERR_SHAPE;
 }
