@@ -53,6 +53,9 @@ struct ConvArgs {
 // of the transposed conv used by dgrad; the replicate-border fold is dgrad_border_fix).
 int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s);
 bool conv3x3_use_wino(const ConvArgs& a, int cout);
+// conv_wino8.hip: Winograd kernels for 32 / 64 output channels whose eight waves all stage and contract (a.wpack = the Winograd pack)
+bool conv3x3_wino8_applies(int nb, int nq);
+int launch_conv3x3_wino8(const ConvArgs& a, int nb, int zero_pad, bool dyf, int grid, int ntiles, int lgx, int lgy, hipStream_t s);
 int conv3x3_wino_kind(const ConvArgs& a, int cout, int zero_pad);   // 0 tap-domain, 1 / 2 Winograd variants (residency differs)
 // workgroups launched == stat_partials rows written; wino = conv3x3_wino_kind() of the same call
 int conv3x3_grid_blocks(int B, int H, int W, int cout, int wino = 0);

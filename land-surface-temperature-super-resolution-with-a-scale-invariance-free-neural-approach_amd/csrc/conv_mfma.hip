@@ -1110,6 +1110,8 @@ int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s
     ConvArgs w = a;
     w.wpack = a.wpack_wino;
     const dim3 wgrid(conv3x3_grid_blocks(a.B, a.H, a.W, cout, conv3x3_wino_kind(a, cout, zero_pad)));
+    // 32 / 64 output channels: the kernel in which all eight waves stage and contract (conv_wino8.hip)
+    if (conv3x3_wino8_applies(nb, a.NQ)) return launch_conv3x3_wino8(w, nb, zero_pad, dyf, (int)wgrid.x, ntiles, lgx, lgy, s);
 #define SIFSR_WINO_LAUNCH(NBV, ZP, DY) hipLaunchKernelGGL((conv3x3_mfma_kernel<NBV, ZP, 0, DY, true>), wgrid, block, 0, s, w, ntiles, lgx, lgy)
 #define SIFSR_WINO_CASE(NBV)                                                                              \
   case NBV:                                                                                               \

@@ -32,7 +32,7 @@ def test_lint_flags_an_asm_result_consumed_by_the_next_mfma():
     assert not [f for f in isa_lint.lint_text(SNIPPET.replace("v12, v188", "v12, v190") % "") if f[2] == "A"]
 
 
-@pytest.mark.parametrize("name", ["conv_mfma.hip", "conv_wgrad_wino.hip"])
+@pytest.mark.parametrize("name", ["conv_mfma.hip", "conv_wino8.hip", "conv_wgrad_wino.hip"])
 def test_no_asm_to_mfma_hazard_in_the_kernels(name):
     src = glob.glob(os.path.join(ROOT, "*_amd", "csrc", name))[0]
     text = isa_lint.compile_to_asm(src)
