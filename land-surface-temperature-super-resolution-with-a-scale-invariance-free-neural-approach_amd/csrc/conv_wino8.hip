@@ -39,7 +39,8 @@ static __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigne
 }
 constexpr unsigned OOB = 0xFFFFFF00u;   // per-lane offset beyond any tensor: buffer loads return 0, stores are dropped
 
-template <int NB, bool ZERO_PAD, bool DYF>
+// DEPTH: items in flight per thread (register sets); 1 everywhere (see the launcher)
+template <int NB, bool ZERO_PAD, bool DYF, int DEPTH>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a, const int ntiles, const int lgx, const int lgy) {
   static_assert(NB == 2 || NB == 4, "32 or 64 output channels");
   static_assert(!DYF || ZERO_PAD, "the fused BatchNorm backward belongs to the input-gradient pass");
@@ -118,12 +119,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
       }
     }
   };
-  float4 stg[3], sty[DYF ? 3 : 1];
+  float4 stgS[DEPTH][3], styS[DYF ? DEPTH : 1][DYF ? 3 : 1];
   int it_t = t, it_q = 0;       // next item to fetch; past the end the last item is fetched again (never used)
-  int tS = t, qS = 0;           // (tile, channel block) of the item held in stg
-  auto issue_loads = [&]() {
+  int tSS[DEPTH], qSS[DEPTH];   // (tile, channel block) of the item held in register set k
+  auto issue_loads = [&](const int k) {
+    float4 (&stg)[3] = stgS[k];
+    float4 (&sty)[DYF ? 3 : 1] = styS[DYF ? k : 0];
     const int q = it_q;
-    tS = it_t; qS = it_q;
+    tSS[k] = it_t; qSS[k] = it_q;
     const bool first = q < a.src[0].nq;
     const int C = first ? a.src[0].C : a.src[1].C;
     const int lgc = 31 - __builtin_clz((unsigned)C) + 2;                       // log2(C * 4 bytes)
@@ -151,8 +154,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
     else if (scp != nullptr && kind < 2) v = ld4((kind ? shp : scp) + ch + 4 * c4);
     coef[q][kind][c4] = v;
   }
-  auto write_stage = [&](float4* Lb) {
-    const int q = qS;
+  auto write_stage = [&](float4* Lb, const int k) {
+    const float4 (&stg)[3] = stgS[k];
+    const float4 (&sty)[DYF ? 3 : 1] = styS[DYF ? k : 0];
+    const int q = qSS[k], tS = tSS[k];
     const bool first = q < a.src[0].nq;
     const bool praw = !DYF && (first ? a.src[0].scale : a.src[1].scale) == nullptr;
     const float4 psc = coef[q][0][cg], psh = coef[q][1][cg];
@@ -225,14 +230,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
   // ---- prologue: item 0 to LDS, item 1 in flight
   const int n_items = ((t_hi - t + t_step - 1) / t_step) * NQ;
   set_tile(t);
-  issue_loads();
+  issue_loads(0);
   __syncthreads();   // the coefficient table is complete
-  write_stage(lds[0]);
-  issue_loads();
+  write_stage(lds[0], 0);
+#pragma unroll
+  for (int i = 1; i <= DEPTH; ++i) issue_loads(i % DEPTH);   // item i lives in set i % DEPTH
   __syncthreads();
 
   int buf = 0, q = 0;
-  for (int j = 0; j < n_items; ++j) {
+  auto do_item = [&](const int j, const int ks) {   // ks = (j + 1) % DEPTH: the register set of item j + 1
     const bool last_q = q + 1 == NQ;
     const int t_next = t + t_step;
     const bool more = j + 1 < n_items;
@@ -244,8 +250,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
     // wave's loads have had one full item to land.)
     const bool stage_first = wave8 >= 4;
     if (stage_first && more) {
-      write_stage(lds[buf ^ 1]);
-      issue_loads();
+      write_stage(lds[buf ^ 1], ks);
+      issue_loads(ks);          // item j + 1 + DEPTH
     }
     __builtin_amdgcn_s_setprio(3);
 #pragma unroll
@@ -313,8 +319,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
 
     // ---- item j + 1 -> the other buffer (everybody finished reading it before the previous barrier), item j + 2 in flight
     if (!stage_first && more) {
-      write_stage(lds[buf ^ 1]);
-      issue_loads();
+      write_stage(lds[buf ^ 1], ks);
+      issue_loads(ks);
     }
 
     if (last_q) {
@@ -352,6 +358,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
     __syncthreads();   // item j + 1 is staged; lds[buf] may be refilled
     buf ^= 1;
     if (last_q) { t = t_next; q = 0; } else ++q;
+  };
+  for (int j = 0; j < n_items; j += DEPTH) {
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k)
+      if (j + k < n_items) do_item(j + k, (k + 1) % DEPTH);   // uniform over the workgroup
   }
 
   // ---- per-workgroup BatchNorm partials (sum, sum of squares) over all tiles this workgroup produced ----
@@ -386,15 +397,21 @@ bool conv3x3_wino8_applies(int nb, int nq) {
 // a.wpack must already point at the Winograd-domain pack; grid as for the other Winograd variants (one workgroup per CU)
 int launch_conv3x3_wino8(const ConvArgs& a, int nb, int zero_pad, bool dyf, int grid, int ntiles, int lgx, int lgy, hipStream_t s) {
   const dim3 g(grid), block(512);
-#define SIFSR_W8(NBV)                                                                                                         \
-  if (nb == NBV) {                                                                                                            \
-    if (dyf) hipLaunchKernelGGL((conv3x3_wino8_kernel<NBV, true, true>), g, block, 0, s, a, ntiles, lgx, lgy);               \
-    else if (zero_pad) hipLaunchKernelGGL((conv3x3_wino8_kernel<NBV, true, false>), g, block, 0, s, a, ntiles, lgx, lgy);    \
-    else hipLaunchKernelGGL((conv3x3_wino8_kernel<NBV, false, false>), g, block, 0, s, a, ntiles, lgx, lgy);                 \
-    SIFSR_LAUNCH_CHECK();                                                                                                     \
-    return SIFSR_OK;                                                                                                          \
+  static const int dbg_depth = getenv("SIFSR_DBG_WINO8_DEPTH") ? atoi(getenv("SIFSR_DBG_WINO8_DEPTH")) : 0;   // 1 / 2: force (A/B)
+  // measured with two items in flight on the one-channel-block layers (where an item is shortest): 1 % slower on the step --
+  // as in conv_mfma.hip, load latency is not what these kernels wait for.  Kept as an A/B knob.
+  const bool deep = nb == 2 && dbg_depth == 2;
+#define SIFSR_W8L(NBV, DV)                                                                                                        \
+  {                                                                                                                               \
+    if (dyf) hipLaunchKernelGGL((conv3x3_wino8_kernel<NBV, true, true, DV>), g, block, 0, s, a, ntiles, lgx, lgy);               \
+    else if (zero_pad) hipLaunchKernelGGL((conv3x3_wino8_kernel<NBV, true, false, DV>), g, block, 0, s, a, ntiles, lgx, lgy);    \
+    else hipLaunchKernelGGL((conv3x3_wino8_kernel<NBV, false, false, DV>), g, block, 0, s, a, ntiles, lgx, lgy);                 \
+    SIFSR_LAUNCH_CHECK();                                                                                                         \
+    return SIFSR_OK;                                                                                                              \
   }
-  SIFSR_W8(2) SIFSR_W8(4)
-#undef SIFSR_W8
+  if (nb == 2 && deep) SIFSR_W8L(2, 2)
+  if (nb == 2) SIFSR_W8L(2, 1)
+  if (nb == 4) SIFSR_W8L(4, 1)
+#undef SIFSR_W8L
   return SIFSR_ERR_SHAPE;
 }
