@@ -91,8 +91,8 @@ print(json.dumps(traffic, indent=1))
 
 # ---- category roll-up ----
 cats = collections.OrderedDict([
-    ("conv fwd (MFMA)", lambda k: "conv3x3_mfma_kernel<" in k and k.split("conv3x3_mfma_kernel<")[1].split(",")[1].strip().startswith("false")),
-    ("conv dgrad (MFMA)", lambda k: "conv3x3_mfma_kernel<" in k and k.split("conv3x3_mfma_kernel<")[1].split(",")[1].strip().startswith("true")),
+    ("conv fwd (MFMA)", lambda k: any(t in k and k.split(t)[1].split(",")[1].strip().startswith("false") for t in ("conv3x3_mfma_kernel<", "conv3x3_wino8_kernel<"))),
+    ("conv dgrad (MFMA)", lambda k: any(t in k and k.split(t)[1].split(",")[1].strip().startswith("true") for t in ("conv3x3_mfma_kernel<", "conv3x3_wino8_kernel<"))),
     ("dgrad border", lambda k: "dgrad_border" in k),
     ("conv wgrad (MFMA)", lambda k: "conv3x3_wgrad" in k),
     ("wgrad slab reduce", lambda k: "wgrad_reduce" in k or "wgrad_wino_reduce" in k or "wgrad_wino_finish" in k),
