@@ -1,0 +1,58 @@
+"""The library's A/B switches select other kernels for the same maths: SIFSR_WGRAD_WINO=0 (tap-domain weight gradients),
+SIFSR_NO_WINO8=1 (producer / consumer Winograd kernels for 32 / 64 output channels), SIFSR_NO_WINO=1 (tap-domain forward and
+input gradients).  The switches are read once per process, so each runs in its own process: the same seeded SR2 step must give
+the same loss and gradients as the default configuration to fp32 rounding (the kernels differ in summation order only), and the
+default itself is pinned to the oracle by tests/test_model_gpu.py."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["SIFSR_ROOT"])
+import sifsr
+torch.manual_seed(11)
+dev = torch.device("cuda", 0)
+model = sifsr.ModelB_2(2, [16, 32, 64, 128], "replicate", "ReLU", 1, 1).to(dev)
+stats = dict(sifsr.dataset.DEFAULT_STATS)
+lst, lst_up, ndvi = sifsr.dataset.synthetic_device_batch(3, dev, seed=21)
+model.train()
+sr = model(torch.cat((lst_up, ndvi), dim=1))
+_, _, loss = sifsr.sif_loss("sr2", sr, lst, ndvi, stats["mean_lst"], stats["std_lst"], 0.5, -0.25)
+loss.backward()
+torch.cuda.synchronize()
+torch.save({"loss": float(loss), "sr": sr.detach().cpu(), "grad": model.flat_grad().detach().cpu().clone()}, os.environ["SIFSR_OUT"])
+'''
+
+
+def _run(tmp_path, tag, extra_env):
+    out = tmp_path / f"{tag}.pt"
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, SIFSR_ROOT=ROOT, SIFSR_OUT=str(out), **extra_env)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return torch.load(out, weights_only=True)
+
+
+def test_kernel_switches_agree_with_the_default_configuration(tmp_path):
+    ref = _run(tmp_path, "default", {})
+    gmax = float(ref["grad"].abs().max())
+    for tag, env in [("tap_wgrad", {"SIFSR_WGRAD_WINO": "0"}), ("no_wino8", {"SIFSR_NO_WINO8": "1"}),
+                     ("no_wino", {"SIFSR_NO_WINO": "1"}), ("single_stream", {"SIFSR_WGRAD_STREAM": "0"})]:
+        got = _run(tmp_path, tag, env)
+        assert abs(got["loss"] - ref["loss"]) <= 1e-5 * abs(ref["loss"]), tag
+        assert float((got["sr"] - ref["sr"]).abs().max()) <= 1e-4 * float(ref["sr"].abs().max()), tag
+        # gradients: a handful of ReLU decisions may flip when the forward kernels differ, so the bar is
+        # on the bulk: relative L2 over all 282,705 parameters
+        rel = float((got["grad"] - ref["grad"]).norm() / ref["grad"].norm())
+        assert rel <= (1e-5 if tag in ("tap_wgrad", "single_stream") else 2e-3), (tag, rel)
+        if tag == "single_stream":
+            assert torch.equal(got["grad"], ref["grad"]), "the second stream must not change a bit"
+        assert float((got["grad"] - ref["grad"]).abs().max()) <= 0.05 * gmax, tag
