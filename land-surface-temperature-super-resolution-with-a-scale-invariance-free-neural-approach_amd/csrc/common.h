@@ -49,6 +49,13 @@ static __device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh
 // a - b on a register pair as ONE instruction: v_pk_add_f32 with the negate modifiers on b.  (hipcc emits v_pk_add_f32 for
 // the sum of two float2 values but scalarises their difference into two v_sub_f32 -- twice the issue slots on a SIMD whose
 // matrix pipe waits for every vector instruction.)  Exact, like the subtraction it replaces.
+#ifdef SIFSR_SCALAR_PK
+// A/B build (tools/build_variant.sh NAME conv_wino8.hip -DSIFSR_SCALAR_PK -fno-slp-vectorize): two scalar adds per pair.  The CDNA
+// guide prices packed fp32 adds beside bf16 MFMAs above their issue slot; beside v_mfma_f32_16x16x4_f32 in these kernels the packed
+// form is the faster one (scalar: forward 64->32 @128^2 247 -> 266 us, 16->32 72 -> 77 us).
+static __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return (f32x2){a[0] - b[0], a[1] - b[1]}; }
+static __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { return (f32x2){a[0] + b[0], a[1] + b[1]}; }
+#else
 static __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
   f32x2 r;
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
@@ -60,6 +67,7 @@ static __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {   // same rea
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+#endif
 
 // BatchNorm + ReLU BACKWARD applied while a consumer stages its operand (the input-gradient and weight-gradient
 // convolutions of layer l read g_l = dL/d relu(bn(y_l)) and y_l instead of a stored dL/dy_l):
