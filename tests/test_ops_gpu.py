@@ -401,7 +401,7 @@ def test_adam_flat(L):
 
 
 @pytest.mark.parametrize("shape", [(16, 16, 256, 256, 2), (16, 16, 128, 128, 8), (32, 16, 256, 256, 1),
-                                   (64, 32, 128, 128, 4), (64, 64, 32, 32, 16), (128, 64, 64, 64, 4)])
+                                   (64, 32, 128, 128, 4), (64, 64, 32, 32, 16), (128, 64, 64, 64, 4), (32, 64, 64, 64, 16)])
 def test_conv3x3_full_size_grids(L, shape):
     """Layer-sized problems: enough tiles that the persistent kernels run two workgroups per CU and several
     tiles per workgroup (the small cases above never do) -- forward and dgrad, repeated to expose races."""
@@ -425,6 +425,30 @@ def test_conv3x3_full_size_grids(L, shape):
         torch.cuda.synchronize()
         assert rel_err(nchw(y.cpu()), y_ref) < TOL
         assert rel_err(nchw(g.cpu()), ga_ref) < TOL
+    # the Winograd-domain kernels the model runs (16 out: two workgroups per CU with the weights in LDS; 32 / 64 out: all eight
+    # waves staging and contracting; weight gradient with the engine's grid of one round of resident workgroups)
+    wr = w.clone().requires_grad_(True)
+    (gw_ref,) = torch.autograd.grad((conv_rep(x, wr) * dy).sum(), [wr])
+    wwf = torch.empty(16 * cin * cout, device="cuda"); wwd = torch.empty(16 * cin * cout, device="cuda")
+    L.call("sifsr_pack_conv_weights_wino", dw_, cin, cout, wwf, wwd, S())
+    nstat = L.call("sifsr_conv3x3_stat_blocks_wino", B, H, W, cin, cout)
+    for _ in range(3):
+        y = torch.full((B, H, W, cout), float("nan"), device="cuda")
+        g = torch.full((B, H, W, cin), float("nan"), device="cuda")
+        part = torch.full((nstat, cout, 2), float("nan"), device="cuda")
+        L.call("sifsr_conv3x3_fwd_wino", dx, cin, None, None, None, 0, None, None, wf, wwf, y, cout, part, B, H, W, S())
+        L.call("sifsr_conv3x3_dgrad_wino", ddy, cout, wd, wwd, cin, g, cin, None, 0, None, B, H, W, S())
+        for nb in (512 if cout < 64 else 256, 97):
+            scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_wino_scratch_floats", cin, cout, nb), device="cuda")
+            dwx = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+            L.call("sifsr_conv3x3_wgrad_wino", dx, cin, None, None, None, 0, None, None, ddy, None, None, cout, scratch, nb, dwx, B, H, W, S())
+            torch.cuda.synchronize()
+            assert rel_err(dwx.cpu(), gw_ref) < TOL, nb
+        assert rel_err(nchw(y.cpu()), y_ref) < TOL
+        assert rel_err(nchw(g.cpu()), ga_ref) < TOL
+        ps = part.sum(0).cpu()
+        assert torch.allclose(ps[:, 0], y_ref.detach().sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+        assert torch.allclose(ps[:, 1], (y_ref.detach() ** 2).sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
 
 
 def _bn_setup(L, rs, y, gamma, beta):
