@@ -471,3 +471,27 @@ def test_wgrad_stream_on_off_bit_identical(sifsr):
     assert out[0][0] == out[1][0] == out[2][0]
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][1], out[2][1])
     assert out[0][1].abs().max().item() > 0
+
+
+def test_training_is_bit_reproducible(sifsr):
+    """Every kernel of the step is deterministic (fixed-order reductions, no atomics on data): the same 12 steps from the same
+    seed end in bit-identical parameters, twice, at a batch that gives every persistent workgroup several tiles and makes the
+    two streams of the backward interleave differently from run to run.  A race in a staging / barrier protocol shows up here
+    as a difference long before it is large enough for a parity bar."""
+    lst, lst_up, ndvi = sifsr.dataset.synthetic_device_batch(8, "cuda", seed=33)
+    stats = {"mean_lst": MEAN, "std_lst": STD}
+    ends = []
+    for _ in range(3):
+        torch.manual_seed(5)
+        m = sifsr.ModelB_2(2, [16, 32, 64, 128], "replicate", "ReLU", 1, 1).cuda()
+        opt = sifsr.FlatAdam(m.parameters(), lr=1e-3)
+        losses = []
+        for _ in range(12):
+            _, _, loss = sifsr.train.train_step(m, opt, lst, lst_up, ndvi, stats, 0.5, -0.25, "sr2")
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        ends.append((losses, m.flat_parameters().detach().clone(), m.inbloc.bloc[1].running_var.detach().clone()))
+    for other in ends[1:]:
+        assert other[0] == ends[0][0]
+        assert torch.equal(other[1], ends[0][1]) and torch.equal(other[2], ends[0][2])
+    assert ends[0][0][-1] < ends[0][0][0]
