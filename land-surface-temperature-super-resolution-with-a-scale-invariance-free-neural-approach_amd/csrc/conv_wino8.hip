@@ -261,6 +261,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
       issue_loads(ks);          // item j + 1 + DEPTH
     }
     __builtin_amdgcn_s_setprio(3);
+#ifdef SIFSR_DBG_NOMFMA
+    if (a.B < 0)   // diagnostic build: the kernel's data movement without its matrix work (results are zeros)
+#endif
 #pragma unroll
     for (int g = 0; g < NGRP; ++g) {
       // ---- the patch's 4x4 input window -> V = B^T d B (in place), as conv_mfma.hip's Winograd consumer
