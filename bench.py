@@ -169,6 +169,9 @@ def main():
                          "forward / input-gradient / weight-gradient passes, fp32 accumulation and storage); bf16x3 = fp32 on the bf16 "
                          "matrix cores (exact three-way bf16 split of every conv operand, six cross products; fp32-level results) "
                          "-- neither is the default")
+    ap.add_argument("--host-io", action="store_true",
+                    help="report, next to the normal line, the rate with every step's inputs starting in (pinned) host memory and, for "
+                         "--mode infer, the result copied back: the PCIe-inclusive figure (never `value`)")
     args = ap.parse_args()
 
     import ctypes
@@ -212,6 +215,44 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    def host_io_rate():
+        """Steps whose inputs start in pinned host memory (two buffer sets: the copy of step i+1 is enqueued on a second stream
+        while step i computes) and, for inference, whose output ends in pinned host memory.  patches (tiles) per second."""
+        n = 20
+        hb = [[t.cpu().pin_memory() for t in (lst, lst_up, ndvi)] for _ in range(2)]
+        db = [[torch.empty_like(t) for t in (lst, lst_up, ndvi)] for _ in range(2)]
+        out_h = torch.empty(batch, 1, 256, 256).pin_memory() if infer else None
+        copy_s = torch.cuda.Stream()
+        ready = [torch.cuda.Event() for _ in range(2)]
+        freed = [torch.cuda.Event() for _ in range(2)]
+
+        def upload(i):
+            k = i & 1
+            with torch.cuda.stream(copy_s):
+                copy_s.wait_event(freed[k])
+                for d_, h_ in zip(db[k], hb[k]):
+                    d_.copy_(h_, non_blocking=True)
+                ready[k].record(copy_s)
+
+        for k in range(2):
+            freed[k].record()
+        fence()
+        t0 = time.perf_counter()
+        upload(0)
+        for i in range(n):
+            k = i & 1
+            if i + 1 < n:
+                upload(i + 1)
+            torch.cuda.current_stream().wait_event(ready[k])
+            a_, b_, c_ = db[k]
+            if infer:
+                out_h.copy_(predictor(b_, c_), non_blocking=True)
+            else:
+                sifsr.train.train_step(model, opt, a_, b_, c_, stats, alpha, gamma, kind)
+            freed[k].record()
+        fence()
+        return n * batch / (time.perf_counter() - t0)
 
     for _ in range(args.warmup):
         step()
@@ -342,6 +383,11 @@ def main():
                 "step": {"hbm_GBs_algorithmic": round(bytes_unit * per_gpu / 1e9, 1),
                          "frac": round(bytes_unit * per_gpu / 1e9 / PEAK_HBM_GBS, 4)},
             }
+        if args.host_io:
+            out_json["host_io"] = {"value": round(host_io_rate(), 2), "unit": out_json["unit"],
+                                   "what": "inputs start in pinned host memory every step (double-buffered async H2D on a second stream)"
+                                           + ("; output copied back to pinned host memory" if infer else "")
+                                           + " -- the PCIe-inclusive rate, not the headline value"}
         if world == 1 and not args.no_cpu_baseline and not infer:
             out_json["cpu_baseline"] = cpu_baseline(kind, alpha, gamma, lr, stats["mean_lst"], stats["std_lst"])
         print(json.dumps(out_json), flush=True)
