@@ -256,11 +256,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
     // the same time with the matrix pipe idle.  (lds[buf ^ 1] is free since the barrier that closed item j - 1; either way a
     // wave's loads have had one full item to land.)
     const bool stage_first = wave8 >= 4;
+    // staging at the higher wave priority: it is a few dozen instructions that decide when the next loads go out; contraction one
+    // step below (still above a co-running weight-gradient kernel at 0).  +0.4 % on the step against the opposite order.
+    __builtin_amdgcn_s_setprio(3);
     if (stage_first && more) {
       write_stage(lds[buf ^ 1], ks);
       issue_loads(ks);          // item j + 1 + DEPTH
     }
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(2);
 #ifdef SIFSR_DBG_NOMFMA
     if (a.B < 0)   // diagnostic build: the kernel's data movement without its matrix work (results are zeros)
 #endif
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
       }
       out_row(3, M[1]);
     }
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(3);
 
     // ---- item j + 1 -> the other buffer (everybody finished reading it before the previous barrier), item j + 2 in flight
     if (!stage_first && more) {
