@@ -29,7 +29,7 @@
 #endif
 
 /* ---- introspection (host only, no GPU touched) -------------------------------------------- */
-SIFSR_API int sifsr_abi_version(void);
+SIFSR_API int sifsr_abi_version(void);   /* 2 since the Winograd-domain and fused BatchNorm-backward entry points (round 2) */
 SIFSR_API int sifsr_num_params(void);   /* 282705 */
 SIFSR_API int sifsr_num_running(void);  /* 1184 = 2 * 592 channels */
 /* out[17][8] = {cin, cout, level, w_off, gamma_off, beta_off, run_off, ch_off}; returns 17 */

@@ -10,7 +10,7 @@ static ConvSrc mk_src(const float* p, int C, const float* sc, const float* sh) {
   return s;
 }
 
-int sifsr_abi_version(void) { return 1; }
+int sifsr_abi_version(void) { return 2; }   // 2: Winograd-domain entry points, fused BatchNorm-backward forms (round 2)
 int sifsr_num_params(void) { return sifsr_net().total_params; }
 int sifsr_num_running(void) { return sifsr_net().total_running; }
 int sifsr_layer_table(int* out, int capacity_rows) {
