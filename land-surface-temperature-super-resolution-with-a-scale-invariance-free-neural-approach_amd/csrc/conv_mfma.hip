@@ -177,7 +177,8 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
     // the same data movement runs at 5.5 TB/s (100 us for 16->16 @256^2, SIFSR_DBG_NOMFMA build); with it 150 us although the
     // matrix work alone is ~75 us -- the consumers' back-to-back MFMAs keep the producers' few staging instructions and the next
     // item's loads from issuing on time.  Producers at 3, consumers at 2: -4 % forward, -6 % input gradient, +0.9 % on the step.
-    if (WINO && NB == 1) __builtin_amdgcn_s_setprio(3);
+    // (the bf16-operand kernels, HBM-bound throughout, take the same arrangement: +0.8 % on the bf16 step)
+    if ((WINO && NB == 1) || MODE == 1) __builtin_amdgcn_s_setprio(3);
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.src[0].ptr, npix * a.src[0].C * 4u);
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.src[1].ptr ? a.src[1].ptr : a.src[0].ptr, npix * (a.src[1].ptr ? a.src[1].C : a.src[0].C) * 4u);
     const __amdgpu_buffer_rsrc_t rsy = make_rsrc(DYF ? a.bw_y : a.src[0].ptr, npix * a.src[0].C * 4u);
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
     // the sched_barrier keeps the compiler from hoisting the loads to the top, which doubles the live weights and
     // spills (measured: +1.3 % on the step, and the NB = 8 variant no longer spills).
     const int qn = last_q ? 0 : q + 1;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(MODE == 1 ? 2 : 3);   // bf16 operands: below this kernel's producers
     if (BF16) {
       // v_mfma_f32_16x16x32_bf16 (16 cycles for K = 32; the K = 16 form of gfx90a takes the same 16): one MFMA contracts the
       // 16 channels of TWO taps.  Lane (i, kq) holds k = 8*kq .. 8*kq+7 = channels 4kq..4kq+3 of the first tap, then of the
