@@ -70,6 +70,16 @@ def _read(file, keys):
     return tuple(data[k] for k in keys)
 
 
+def read_JsonA(file):
+    """utils.py:718-739."""
+    return _read(file, ("dataset_parameter", "modelA_parameters", "hyperparameters", "save_parameters", "device"))
+
+
+def read_JsonC(file):
+    """utils.py:767-787."""
+    return _read(file, ("dataset_parameter", "modelC_parameters", "hyperparameters", "save_parameters", "device"))
+
+
 def read_JsonB(file):
     """utils.py:741-764: (dataset_parameter, modelA_parameters, modelB_parameters, hyperparameters, save_parameters, device)."""
     return _read(file, ("dataset_parameter", "modelA_parameters", "modelB_parameters", "hyperparameters", "save_parameters", "device"))
@@ -86,7 +96,15 @@ def load_model(model, state_dict_file, device="cpu"):
     model.load_state_dict(torch.load(state_dict_file, map_location=torch.device(device), weights_only=True))
 
 
+class OutOfScopeAttribute(AttributeError, NotImplementedError):
+    """Raised for names of the reference's utils.py that the MI355X build does not provide.  An AttributeError, so that
+    ``hasattr``, ``from utils import *`` (which probes ``__all__``) and ``inspect`` see an ordinary missing attribute; also a
+    NotImplementedError, for callers that catch that."""
+
+
 def __getattr__(name):
-    raise NotImplementedError(
+    if name.startswith("__"):
+        raise AttributeError(name)
+    raise OutOfScopeAttribute(
         f"utils.{name}: not part of the SIF-CNN-SR hot path (GDAL / OpenCV / rasterio I/O, classical baselines and plots "
         "are out of scope of the MI355X build, SURVEY.md §2); use the reference's own utils.py for it")

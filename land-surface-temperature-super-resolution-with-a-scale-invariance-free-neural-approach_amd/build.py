@@ -24,15 +24,18 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra=()):
+def build(force=False, verbose=False, extra=(), lib=None, obj_dir=None):
+    """lib / obj_dir: build a VARIANT of the library elsewhere (tools/build_ab.sh: same-device A/B through SIFSR_LIB)."""
+    LIB_ = lib or LIB
+    OBJ_ = obj_dir or OBJ
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "sifsr_hip.h"))
-    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(OBJ_, exist_ok=True)
     jobs = []
     for f in srcs:
-        src, obj = os.path.join(CSRC, f), os.path.join(OBJ, f[:-4] + ".o")
+        src, obj = os.path.join(CSRC, f), os.path.join(OBJ_, f[:-4] + ".o")
         if force or _stale(obj, [src] + hdrs):
             jobs.append([hipcc, *FLAGS, *extra, "-c", src, "-o", obj])
 
@@ -45,10 +48,10 @@ def build(force=False, verbose=False, extra=()):
 
     with cf.ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ, f[:-4] + ".o") for f in srcs]
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    objs = [os.path.join(OBJ_, f[:-4] + ".o") for f in srcs]
+    if force or jobs or _stale(LIB_, objs):
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_, *objs])
+    return LIB_
 
 
 if __name__ == "__main__":

@@ -46,25 +46,47 @@ static __device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh
   return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 
-// a - b on a register pair as ONE instruction: v_pk_add_f32 with the negate modifiers on b.  (hipcc emits v_pk_add_f32 for
-// the sum of two float2 values but scalarises their difference into two v_sub_f32 -- twice the issue slots on a SIMD whose
-// matrix pipe waits for every vector instruction.)  Exact, like the subtraction it replaces.
-#ifdef SIFSR_SCALAR_PK
-// A/B build (tools/build_variant.sh NAME conv_wino8.hip -DSIFSR_SCALAR_PK -fno-slp-vectorize): two scalar adds per pair.  The CDNA
-// guide prices packed fp32 adds beside bf16 MFMAs above their issue slot; beside v_mfma_f32_16x16x4_f32 in these kernels the packed
-// form is the faster one (scalar: forward 64->32 @128^2 247 -> 266 us, 16->32 72 -> 77 us).
+// a - b / a + b on a register pair as ONE packed instruction.  (hipcc emits v_pk_add_f32 for most sums of two float2 values but
+// scalarises every float2 difference into two v_sub_f32 -- twice the issue slots on a SIMD whose matrix pipe waits for every
+// vector instruction.)  Exact, like the operations they replace.  SIFSR_PK_MODE selects the form (A/B builds, tools/build_ab.sh):
+//   0  inline assembly v_pk_add_f32 (neg modifiers for the difference).  An asm statement is opaque to LLVM's hazard
+//      recognizer: nothing pads a matrix-pipe hazard between it and the MFMAs around it; tools/isa_lint.py checks the
+//      compiled code instead (tests/test_isa_hazards.py).
+//   1  the same followed by `s_nop 1`: two wait states before ANY later instruction can read the result -- what LLVM itself
+//      inserts between a vector write and an MFMA that reads it -- so the result -> MFMA hazard is padded by construction.
+//   2  compiler-visible: fma(b, -+1, a) = one v_pk_fma_f32, the +-1 out of a scalar asm move so that LLVM cannot fold the product
+//      away (with literal constants it does, and falls back to scalarised subtractions).  Round-3 finding: correct and fully
+//      padded by the compiler, but it reschedules the transforms and the 64-channel Winograd kernels go from 255 registers to
+//      256 + 85..136 spilled -- kept for A/B only.
+//   3  two scalar adds per pair (round-2 A/B: 7-8 % slower per layer beside v_mfma_f32_16x16x4_f32).
+#ifndef SIFSR_PK_MODE
+#define SIFSR_PK_MODE 1
+#endif
+#if SIFSR_PK_MODE == 3
 static __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return (f32x2){a[0] - b[0], a[1] - b[1]}; }
 static __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { return (f32x2){a[0] + b[0], a[1] + b[1]}; }
+#elif SIFSR_PK_MODE == 2
+static __device__ __forceinline__ f32x2 pk_unit(bool minus) {
+  float r;
+  if (minus) asm("s_mov_b32 %0, -1.0" : "=s"(r)); else asm("s_mov_b32 %0, 1.0" : "=s"(r));
+  return (f32x2){r, r};
+}
+static __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return __builtin_elementwise_fma(b, pk_unit(true), a); }
+static __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { return __builtin_elementwise_fma(b, pk_unit(false), a); }
 #else
+#if SIFSR_PK_MODE == 1
+#define SIFSR_PK_PAD "\n\ts_nop 1"
+#else
+#define SIFSR_PK_PAD ""
+#endif
 static __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
   f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" SIFSR_PK_PAD : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-
 static __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {   // same reason: not every float2 sum comes out packed
   f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  asm("v_pk_add_f32 %0, %1, %2" SIFSR_PK_PAD : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 #endif

@@ -124,14 +124,17 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
     for (int k = 0; k < 3; ++k) w.gP[k] = take(pc[k] * N[k + 1]);
     w.gU[0] = take(64 * N[2]); w.gU[1] = take(32 * N[1]); w.gU[2] = take(16 * N[0]);
     w.slabs = take(1024 * 288);   // edge-layer partials
-    w.slab_l[0] = 0;
+    w.slab_l[0] = 0; w.slab_cap[0] = 0;
     size_t wino_pairs = 0;
     for (int l = 1; l < SIFSR_NUM_BN_LAYERS; ++l) {
       const int lvh = H >> nt.L[l].level, lvw = W >> nt.L[l].level;
       const int ntiles = B * ((lvh + 7) / 8) * ((lvw + 15) / 16);
       // upper bound over chunkings (x-dim blocks * chunks <= blocks at one chunk)
       // (16 values per weight pair: the Winograd F(3x3,2x2) form; the tap-domain form uses 9 of them)
-      w.slab_l[l] = take((size_t)wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles) * 16 * nt.L[l].cin * nt.L[l].cout);
+      // ... and over the two kernel families: the tap-domain grid scales with SIFSR_DBG_WGRAD_GRID_PCT, the Winograd one does not
+      const int nb_tap = wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles, false), nb_wino = wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles, true);
+      w.slab_cap[l] = (size_t)(nb_tap > nb_wino ? nb_tap : nb_wino) * 16 * nt.L[l].cin * nt.L[l].cout;
+      w.slab_l[l] = take(w.slab_cap[l]);
       wino_pairs += (size_t)nt.L[l].cin * nt.L[l].cout;
     }
     w.wgm = take(2 * 16 * wino_pairs);
@@ -253,7 +256,7 @@ struct SideLaneGuard {
 // Up to PROF_SLOTS (layer, phase) selections are timed side by side.  The event pairs are created by
 // sifsr_engine_profile_select / _add (i.e. before the caller's timed region), never inside a launch; a launch that finds
 // its pool exhausted is simply not timed.  One mutex serialises selection, use and read.
-constexpr int PROF_SLOTS = 8;
+constexpr int PROF_SLOTS = 24;
 constexpr size_t PROF_POOL = 1024;   // launches of one selected kernel that can be timed before the next select
 struct ProfSlot {
   int layer = -1, phase = 0;
@@ -374,6 +377,8 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
   const bool wino = c.xjobs != nullptr && wgrad_wino_policy(L.cin, L.cout) && conv3x3_wgrad_use_wino(a, L.cin, L.cout);
   const int nbi = wino ? wgrad_wino_nbi_chunk(a, L.cin) : wgrad_nbi_chunk(a, L.cin);
   const int nblk = wgrad_blocks(L.cin, L.cout, L.cin / (16 * nbi), a.ntiles, wino);
+  // every workgroup (x cin chunks) writes one slab of (16 | 9) * cin_chunk * cout floats into this layer's region
+  if ((size_t)nblk * (L.cin / (16 * nbi)) * (wino ? 16 : 9) * (16 * nbi) * L.cout > c.lay.slab_cap[l]) return SIFSR_ERR_WORKSPACE;
   hipStream_t ws = c.s;
   if (c.side != nullptr && c.jobs != nullptr) {   // dy_l is complete on the main stream at this point
     if (hipEventRecord(c.side->ev[l], c.s) != hipSuccess || hipStreamWaitEvent(c.side->s, c.side->ev[l], 0) != hipSuccess)

@@ -34,15 +34,61 @@ def init_from_env(backend: str | None = None):
     return rank, world, local
 
 
+class AllreduceTimer:
+    """Optional timing of the gradient exchange (bench.py, N > 1): a pool of event pairs created up front, one pair
+    recorded on the caller's stream around every collective while installed (``set_allreduce_timer``).  The collective
+    runs on RCCL's own stream, which waits for the caller's stream and is waited for by it, so the pair brackets the
+    exchange *including* the wait for the slowest rank.  ``mean_ms()`` synchronises the recorded pairs."""
+
+    def __init__(self, capacity: int = 4096):
+        self._ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(capacity)]
+        self._n = 0
+
+    def reset(self):
+        self._n = 0
+
+    def bracket(self):
+        if self._n >= len(self._ev):
+            return None
+        pair = self._ev[self._n]
+        self._n += 1
+        return pair
+
+    def times_ms(self):
+        out = []
+        for a, b in self._ev[:self._n]:
+            b.synchronize()
+            out.append(a.elapsed_time(b))
+        return out
+
+    def mean_ms(self):
+        t = self.times_ms()
+        return sum(t) / len(t) if t else 0.0
+
+
+_timer: AllreduceTimer | None = None
+
+
+def set_allreduce_timer(timer: AllreduceTimer | None):
+    """Install (or remove, with None) the timer the gradient all-reduce records into."""
+    global _timer
+    _timer = timer
+
+
 def _sum_all_reduce_(flat: torch.Tensor):
     """Sum all-reduce in place.  RCCL reduces device memory directly; the gloo rehearsal path stages device
     tensors through the host (gloo in this build has no device support)."""
+    pair = _timer.bracket() if (_timer is not None and flat.is_cuda) else None
+    if pair is not None:
+        pair[0].record()
     if flat.is_cuda and dist.get_backend() == "gloo":
         host = flat.detach().cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM)
         flat.copy_(host)
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if pair is not None:
+        pair[1].record()
 
 
 def world_size() -> int:

@@ -76,14 +76,14 @@ class ModelCheckpoint:
         if epoch == 1:                                   # first epoch: always the best so far, state untouched
             self.best_epoch, self.saved_best_value = epoch, value
             self.saved_state = copy.deepcopy(model.state_dict())
-        elif value < self.saved_best_value:
+        elif value >= self.saved_best_value:             # the reference's own test (utils.py:687): a NaN metric fails it and
+            self.curr_patience += 1                      # therefore counts as an IMPROVEMENT there -- mirrored, not "fixed"
+            spent = self.curr_patience >= self.patience
+            self.train_state = "break" if spent or epoch == self.max_epochs else "continue"
+        else:
             self.best_epoch, self.saved_best_value, self.curr_patience = epoch, value, 0
             self.saved_state = copy.deepcopy(model.state_dict())
             self.train_state = "continue"
-        else:
-            self.curr_patience += 1
-            spent = self.curr_patience >= self.patience
-            self.train_state = "break" if spent or epoch == self.max_epochs else "continue"
 
 
 def train_epoch(model, loader, optimizer, stats, alpha, gamma, kind="sr2", device="cuda", with_metrics=True):
@@ -148,8 +148,8 @@ def fit(model, train_dataset, val_dataset, n_epochs, batch_size, optimizer, alph
                 metrics["best_epoch"] = checkpoint.best_epoch
                 model.load_state_dict(checkpoint.saved_state)
                 break
-        if epoch == n_epochs:
-            metrics["best_epoch"] = n_epochs
+            if checkpoint.train_state == "continue" and epoch == n_epochs:    # train_model_B_gradFTM.py:342-344: the key exists
+                metrics["best_epoch"] = n_epochs                              # only then (a one-epoch run leaves train_state None)
     return model, metrics
 
 

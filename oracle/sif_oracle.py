@@ -112,6 +112,25 @@ def synthetic_state(seed: int) -> "OrderedDict[str, torch.Tensor]":
     return sd
 
 
+def matched_state(stats: dict, seed: int) -> "OrderedDict[str, torch.Tensor]":
+    """A synthetic state_dict whose every tensor has the first two moments and the range of a TRAINED checkpoint of the
+    reference (``stats[key] = [mean, std, min, max]``, measured by tests/golden/make_golden_real.py on
+    models/modelB_2609 / modelB_1009 -- the weights themselves must not travel, their 104 x 4 summary numbers are data):
+    N(mean, std) from a seeded numpy stream, clipped to [min, max]; ``num_batches_tracked`` takes the stored count.  Puts the
+    parity checks at the reference's own operating point (BatchNorm gains near 1 with trained spreads, running variances
+    well away from 1, conv weights 2-3x smaller than the He init of ``synthetic_state``)."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for key, shape, dtype in state_dict_spec():
+        mean, std, lo, hi = stats[key]
+        if key.endswith("num_batches_tracked"):
+            sd[key] = torch.tensor(int(round(mean)), dtype=torch.int64)
+            continue
+        v = mean + std * rs.standard_normal(tuple(shape)).astype(np.float64)
+        sd[key] = torch.from_numpy(np.clip(v, lo, hi).astype(np.float32))
+    return sd
+
+
 def synthetic_batch(seed: int, batch: int, hr: int = 256):
     """Seeded (lst, lst_up, ndvi) with the ModisDatasetB.__getitem__ shapes (dataset.py:101-142).
 

@@ -50,6 +50,31 @@ def import_reference():
     return ref_model, ref_utils
 
 
+def reference_sobel_filters():
+    """The literal ``filters = [...]`` of /root/reference/train_model_B_predef_filters.py:38-42, read as DATA: the script cannot
+    be imported (it imports GDAL-backed modules and opens absent dataset files at import), so its source is parsed with
+    ``ast`` and the module-level assignment is evaluated with ``ast.literal_eval`` -- nothing of the file is executed.  The
+    SR1 goldens are therefore pinned by the reference's own filter bank, not by the oracle's copy of it."""
+    import ast
+    with open(os.path.join(REF, "train_model_B_predef_filters.py")) as f:
+        tree = ast.parse(f.read())
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and any(isinstance(t, ast.Name) and t.id == "filters" for t in node.targets):
+            return ast.literal_eval(node.value)
+    raise RuntimeError("no module-level `filters = [...]` in the reference's train_model_B_predef_filters.py")
+
+
+REF_FILTERS = None      # set by main() / the other generators (reference_sobel_filters())
+
+
+def _filters():
+    global REF_FILTERS
+    if REF_FILTERS is None:
+        REF_FILTERS = reference_sobel_filters()
+        assert REF_FILTERS == O.SOBEL_FILTERS, "oracle.SOBEL_FILTERS differs from the reference's filter bank"
+    return REF_FILTERS
+
+
 def rel(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
@@ -68,7 +93,7 @@ def ref_loss(ref_utils, kind, sr, lst, ndvi, mean, std, alpha, gamma):
         g_l = sr - ref_utils.get_output_ftm(sr, mtf=0.25)
         g_n = ndvi - ref_utils.get_output_ftm(ndvi, mtf=0.25)
     else:
-        filters = O.SOBEL_FILTERS
+        filters = _filters()                        # the reference's own literal (train_model_B_predef_filters.py:38-42)
         ft = torch.zeros((len(filters), 1, 3, 3))
         for i in range(len(ft)):
             ft[i, 0] = torch.tensor(filters[i], dtype=torch.float)
@@ -98,6 +123,7 @@ def main():
     ora_spec = [(k, list(s), str(d)) for k, s, d in O.state_dict_spec()]
     assert ref_spec == ora_spec, "state_dict layout mismatch"
     assert [n for n, _ in m0.named_parameters()] == O.param_names()
+    out["sobel_filters"] = _filters()            # parsed from the reference's script (data: 4 x 3 x 3 integers)
     out["state_dict_spec"] = ref_spec
     out["n_params"] = sum(p.numel() for p in m0.parameters())
 
@@ -133,7 +159,7 @@ def main():
     for name, fr, fo, inp in (
             ("downscale_mtf0.1", lambda t: ref_utils.downscale_LST_SR_to_LR(t), lambda t: O.downscale_LST_SR_to_LR(t), xk),
             ("ftm_mtf0.25", lambda t: ref_utils.get_output_ftm(t, mtf=0.25), lambda t: O.get_output_ftm(t, mtf=0.25), x),
-            ("sobel", lambda t: F.conv2d(t, torch.tensor(O.SOBEL_FILTERS, dtype=torch.float)[:, None], padding="same"),
+            ("sobel", lambda t: F.conv2d(t, torch.tensor(_filters(), dtype=torch.float)[:, None], padding="same"),
              O.sobel_bank, x)):
         a = inp.clone().requires_grad_(True)
         yr = fr(a)

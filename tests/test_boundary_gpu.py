@@ -70,7 +70,9 @@ def test_config1_one_epoch_batch8_16_pairs(sifsr):
     opt = sifsr.FlatAdam(m.parameters(), lr=lr)
     ckpt = sifsr.train.ModelCheckpoint(1, 30)
     m, metrics = sifsr.train.fit(m, train_ds, val_ds, 1, bs, opt, alpha, gamma, "sr2", "cuda", ckpt, shuffle=False)
-    assert metrics["best_epoch"] == 1 and ckpt.best_epoch == 1 and len(ckpt.saved_state) == 104
+    # a one-epoch run leaves train_state None in the reference's checkpoint, so its train() never sets metrics['best_epoch']
+    # (train_model_B_gradFTM.py:342-344) -- mirrored
+    assert "best_epoch" not in metrics and ckpt.best_epoch == 1 and ckpt.train_state is None and len(ckpt.saved_state) == 104
     for k in ("train_loss", "train_dsloss", "train_perceploss", "train_psnr", "train_ssim",
               "val_loss", "val_dsloss", "val_perceploss", "val_psnr", "val_ssim"):
         assert len(metrics[k]) == 1 and np.isfinite(metrics[k][0]), k
@@ -305,3 +307,44 @@ def test_capture_with_live_earlier_graph_is_refused(sifsr):
     g2.replay()
     torch.cuda.synchronize()
     assert torch.isfinite(out)
+
+
+def test_fit_early_stop_restores_the_best_state(sifsr):
+    """train.fit over 3 epochs with patience 1 and a learning rate large enough to make the validation loss rise: the loop
+    must switch train -> eval -> train every epoch, break when the patience is spent and load the saved best state back into
+    the flat parameter buffer (train_model_B_gradFTM.py:338-352) -- parameters AND BatchNorm buffers equal the checkpoint's
+    copy, and the nn.Parameters still alias the flat buffer afterwards (the next step trains the restored weights)."""
+    train_ds = sifsr.dataset.ModisDatasetB("data/ModisDatasetB.csv", transf="norm", split="Train", time="day", length=8)
+    val_ds = sifsr.dataset.ModisDatasetB("data/ModisDatasetB.csv", transf="norm", split="Val", time="day", length=8)
+    m = sifsr.ModelB_2(2, [16, 32, 64, 128], "replicate", "ReLU", 1, 1)
+    m.load_state_dict(O.synthetic_state(11))
+    m = m.to("cuda")
+    opt = sifsr.FlatAdam(m.parameters(), lr=0.5)            # absurd on purpose: epoch 2 / 3 validate worse than epoch 1
+
+    class Recording(sifsr.train.ModelCheckpoint):
+        seen = []
+
+        def test_update(self, model, metrics, key, epoch):
+            assert not model.training                       # called right after the validation pass (eval mode)
+            super().test_update(model, metrics, key, epoch)
+            Recording.seen.append((epoch, metrics[key][-1], self.train_state))
+
+    ck = Recording(3, patience=1)
+    m, metrics = sifsr.train.fit(m, train_ds, val_ds, 3, 4, opt, 0.5, -0.25, "sr2", "cuda", ck, shuffle=False)
+    vals = metrics["val_loss"]
+    assert len(vals) >= 2 and all(np.isfinite(v) or np.isnan(v) for v in vals)
+    assert ck.train_state == "break", (Recording.seen, vals)
+    assert metrics["best_epoch"] == ck.best_epoch and len(metrics["train_loss"]) == len(vals) == ck.curr_epoch
+    sd = m.state_dict()
+    for k, v in ck.saved_state.items():
+        assert torch.equal(sd[k].cpu(), v.cpu()), k
+    flat = m.flat_parameters()
+    off = 0
+    for p_ in m.parameters():                                # still views of the one flat buffer
+        assert p_.data_ptr() == flat.data_ptr() + 4 * off
+        off += p_.numel()
+    before = flat.clone()
+    lst, lst_up, ndvi = (torch.from_numpy(np.stack([train_ds[i][j] for i in range(4)])).cuda() for j in range(3))
+    sifsr.train.train_step(m, sifsr.FlatAdam(m.parameters(), lr=1e-3), lst, lst_up, ndvi, train_ds.stats, 0.5, -0.25, "sr2")
+    torch.cuda.synchronize()
+    assert not torch.equal(m.flat_parameters(), before)

@@ -157,3 +157,24 @@ def test_rccl_backend_single_rank(tmp_path):
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "rccl single-rank ok" in r.stdout
+
+
+def test_bench_gpus_2_as_the_driver_starts_it():
+    """`python bench.py --gpus 2 --steps 3` with NO launcher environment -- the driver's command form -- must start its own
+    two rank processes (a child torch.distributed.run, before the parent touches HIP), run the data-parallel step and let
+    rank 0 print the one JSON line with the N > 1 fields.  Two ranks share this box's single GPU, so the collective backend is
+    the gloo rehearsal (RCCL needs one GPU per rank); everything else is the N = 8 code path."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(SIFSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["dist_backend"] == "gloo" and j["rccl_ranks"] == 0            # "nccl" / 2 on a node with one GPU per rank
+    assert j["allreduce_ms"] > 0 and j["rank_ms_per_step_max"] >= j["rank_ms_per_step_min"] > 0
+    assert abs(j["value"] - 2 * 8 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-2 * j["value"]   # whole-job patches / max-rank time
+    assert "cpu_baseline" not in j and "also" not in j                      # N = 1 only

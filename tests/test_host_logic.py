@@ -2,13 +2,17 @@
 PSF taps, synthetic dataset contract, shard arithmetic."""
 import copy
 import io
+import os
 import pickle
+import sys
 
 import numpy as np
 import pytest
 import torch
 
 from oracle import sif_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -202,11 +206,68 @@ def test_dropin_utils_host_functions(golden, tmp_path):
         ck.test_update(m, {"val_loss": [1.0]}, "val_loss", 1)
         ck.test_update(m, {"val_loss": [1.0, 1.5]}, "val_loss", 2)
         assert ck.train_state == "break" and ck.best_epoch == 1
+        # a NaN metric: the reference tests `value >= best` (False for NaN) and so treats it as an improvement -- mirrored
+        ck = us.model_checkpoint(5, patience=1)
+        ck.test_update(m, {"val_loss": [1.0]}, "val_loss", 1)
+        ck.test_update(m, {"val_loss": [1.0, float("nan")]}, "val_loss", 2)
+        assert ck.best_epoch == 2 and ck.curr_patience == 0 and ck.train_state == "continue"
         with pytest.raises(NotImplementedError, match="read_NIRRED"):
             us.read_NIRRED("x.hdf")
+        # ... which is an AttributeError too, so the usual attribute protocols keep working on the overlay
+        assert not hasattr(us, "read_NIRRED") and not hasattr(us, "__wrapped__") and getattr(us, "__all__", None) is None
+        import inspect
+        assert inspect.unwrap(us) is us
+        ns = {}
+        exec("from utils import *", ns)
+        assert "read_JsonB" in ns and "downscale_LST_SR_to_LR" in ns
+        assert us.read_JsonA(str(f))[1] == ma and len(us.read_JsonA(str(f))) == 5
+        with pytest.raises(KeyError):
+            us.read_JsonC(str(f))                                                # paramsB.json has no modelC_parameters, as in the reference
     finally:
         sys.path.remove(os.path.join(root, "dropin"))
         for k, v in saved.items():
             sys.modules.pop(k, None)
             if v is not None:
                 sys.modules[k] = v
+
+
+def test_bench_gpus_n_spawns_ranks_instead_of_exiting():
+    """`python bench.py --gpus 2` (the driver's command form, no launcher environment) must START two rank processes -- a
+    child `torch.distributed.run` created before the parent imports torch -- not exit with "launch with torchrun".  The
+    dry-run flag lets the ranks rendezvous over gloo and sum their ranks without a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-launch"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    j = json.loads(line[0])
+    assert j == {"dry_run": True, "world": 2, "n_gpus": 2, "rank_sum": 1.0}
+    # and the parent must not have imported torch before deciding to spawn
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def main()")]
+    assert "\nimport torch" not in head and "\nfrom torch" not in head
+
+
+def test_bench_roofline_class_selection(tmp_path):
+    """bench.dominant_class() sums TotalDurationNs per kernel CLASS (all CSV rows carrying the class prefix) and returns the
+    largest; the class table covers every MFMA launch of a step exactly once and its FLOPs add up to SURVEY.md §8 d."""
+    import bench
+    t = bench.class_table()
+    launches = [lp for v in t.values() for lp in v]
+    assert len(launches) == len(set(launches)) == 48
+    flops = (sum(bench.layer_flops(l) for l, _ in launches) + 2 * bench.layer_flops(0)     # the 2->16 layer has no input gradient
+             + 3 * 2 * 9 * 16 * 1 * 256 * 256)                                           # outlay (16->1), three passes
+    assert flops == bench.TRAIN_FLOPS_PER_PATCH
+    assert sum(bench.layer_flops(l) for l, p in t["conv3x3_wgrad_wino_kernel<2, 2, true"]) * 64 == 120_795_955_200
+    f = tmp_path / "x_kernel_stats.csv"
+    f.write_text('"Name","Calls","TotalDurationNs"\n'
+                 '"void (anonymous namespace)::conv3x3_mfma_kernel<1, true, 0, true, true>(ConvArgs)",4,500\n'
+                 '"void (anonymous namespace)::conv3x3_mfma_kernel<1, true, 0, false, true>(ConvArgs)",1,450\n'
+                 '"void (anonymous namespace)::conv3x3_wino8_kernel<4, true, true, 1>(ConvArgs)",5,300\n'
+                 '"void (anonymous namespace)::conv3x3_wino8_kernel<4, true, false, 1>(ConvArgs)",1,250\n'
+                 '"bn_finalize_kernel",100,9999\n')
+    cls, src = bench.dominant_class(str(f))
+    assert cls == "conv3x3_wino8_kernel<4, true" and src == "x_kernel_stats.csv"      # 300 + 250 > 500 > 450

@@ -162,3 +162,56 @@ def test_update_check_rejects_a_sign_error(golden):
     with pytest.raises(AssertionError):
         C.update_parity(few, upd_ref, sig, p0 + few, p_ref, c["lr"], 1)
     C.update_parity(upd_ref, upd_ref, sig, p_ref, p_ref, c["lr"], 1)
+
+
+def test_sobel_filters_are_the_references(golden):
+    """golden["sobel_filters"] was parsed (ast.literal_eval) out of the reference's train_model_B_predef_filters.py:38-42 by
+    tests/golden/make_golden.py; the oracle's bank, which the SR1 checks use everywhere, must be that literal."""
+    assert O.SOBEL_FILTERS == golden["sobel_filters"] and np.array(golden["sobel_filters"]).shape == (4, 3, 3)
+
+
+def _real():
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "golden_real_v1.json")) as f:
+        g = json.load(f)
+    with open(os.path.join(here, "real_weight_stats_v1.json")) as f:
+        st = json.load(f)["checkpoints"]
+    return g, st
+
+
+def test_statistics_matched_state_vs_reference():
+    """The oracle at the reference's own operating point: synthetic states with the per-tensor moments and ranges of the
+    shipped trained checkpoints (oracle.matched_state from real_weight_stats_v1.json).  The generator asserted
+    oracle == reference bit-for-bit under the REAL weights and under these states; here the oracle is re-checked against the
+    reference's stored outputs (eval forward, train forward, losses, 53 gradients, BN buffers) on any machine."""
+    g, st = _real()
+    assert g["real_pairs"]["safe_loader"].startswith("refused")        # the real pairs were not unpickled (recorded)
+    for kind in ("sr2", "sr1"):
+        c = g["cases"][f"matched_{kind}"]
+        stats = st[c["checkpoint"]]
+        sd = O.matched_state(stats, c["wseed"])
+        # the state really has the checkpoint's moments: per-tensor mean within 4 standard errors (+ what the clipping to
+        # [min, max] moves), std within 25 % for tensors of at least 64 elements
+        for k, v in sd.items():
+            mean, std, lo, hi = stats[k]
+            if k.endswith("num_batches_tracked"):
+                assert int(v) == int(round(mean))
+                continue
+            v = v.double()
+            assert float(v.min()) >= lo - 1e-6 * max(1.0, abs(lo)) and float(v.max()) <= hi + 1e-6 * max(1.0, abs(hi)), k
+            if v.numel() >= 64 and std > 0:
+                assert abs(float(v.mean()) - mean) < 5 * std / v.numel() ** 0.5 + 0.1 * std, k
+                assert 0.7 * std < float(v.std()) < 1.3 * std, k
+        lst, lst_up, ndvi = O.synthetic_batch(c["bseed"], c["B"])
+        y = O.modelb2_forward({k: v.clone() for k, v in sd.items()}, torch.cat((lst_up, ndvi), 1), training=False)
+        check_digest(y, c["y_eval"], TOL)
+        sr, (ds, pl, loss), grads = O.forward_backward(sd, lst, lst_up, ndvi, g["mean"], g["std"], c["alpha"], c["gamma"], kind)
+        check_digest(sr, c["sr"], TOL)
+        for got, key in ((ds, "ds"), (pl, "pl"), (loss, "loss")):
+            assert abs(float(got) - c[key]) <= 1e-5 * abs(c[key]), (key, float(got), c[key])
+        for n, d in c["grads"].items():
+            check_digest(grads[n], d, 5e-3)      # as test_train_*: other BLAS / thread counts may flip a ReLU (DESIGN.md §6)
+        for k, d in c["bn_buffers"].items():
+            check_digest(sd[k].float(), d, 1e-5)
