@@ -21,8 +21,8 @@ Extra objects in that line:
   roofline     -- the dominant kernel CLASS of the step: per-class sums of TotalDurationNs over the newest two-stream
                   profiles/*_kernel_stats.csv, the class's launches (engine layer table below) ALL timed with HIP events on
                   their launch stream INSIDE the timed steps (sifsr_profile_*): class algorithmic FLOPs per step / class
-                  time per step vs the fp32 MFMA peak.  `kernels` carries the forward / input-gradient / weight-gradient
-                  launches of inbloc.bloc.3 (16->16 @256^2) side by side, `step` the whole-step ratio (SURVEY.md §8 d FLOPs
+                  time per step vs the fp32 MFMA peak.  `kernels` carries the launches of inbloc.bloc.3 (16->16 @256^2: forward, and
+                  the fused input + weight gradient) and ub3.convbloc.bloc.0 (32->16 @256^2) side by side, `step` the whole-step ratio (SURVEY.md §8 d FLOPs
                   per patch), `traffic` the PMC-measured HBM bytes per launch of that class from the newest committed
                   profiles/*_traffic.json (rocprofv3 --pmc passes of this same command; PMC counters cannot be collected
                   from inside the run).
@@ -78,12 +78,24 @@ def layer_flops(layer, hw=256):
     return 2 * 9 * LAYER_CIN[layer] * LAYER_COUT[layer] * side * side
 
 
+FUSED_BWD16 = (1, 2, 3, 16)     # 16 -> 16 layers at 256^2 / 128^2: input AND weight gradient in one launch (conv_bwd16.hip)
+
+
+def member_flops(layer, phase, hw=256):
+    """Algorithmic FLOPs per patch of the launch that (layer, phase) names: both backward passes for a fused 16 -> 16 layer."""
+    return layer_flops(layer, hw) * (2 if layer in FUSED_BWD16 and phase == 2 else 1)
+
+
 def kernel_class(layer, phase):
-    """rocprofv3 kernel-name prefix of the launch the fp32 engine issues for (layer, phase) at even image sizes
-    (engine.hip conv_unit_fwd / _dgrad / _wgrad; conv_mfma.hip / conv_wino8.hip / conv_wgrad_wino.hip dispatch)."""
+    """rocprofv3 kernel-name prefix of the launch the fp32 engine issues for (layer, phase) at 256x256 patches (engine.hip
+    conv_unit_fwd / _dgrad / _wgrad / _bwd16; conv_mfma.hip / conv_wino8.hip / conv_wgrad_wino.hip / conv_bwd16.hip dispatch).
+    None: no launch of its own (the first thin conv; the weight gradient of a fused 16 -> 16 layer, which is part of the
+    layer's (layer, 2) launch)."""
     cin, cout = LAYER_CIN[layer], LAYER_COUT[layer]
     if layer == 0:
         return None                                                  # the thin first conv is not an MFMA unit of these classes
+    if layer in FUSED_BWD16 and phase != 1:
+        return "conv3x3_bwd16_kernel" if phase == 2 else None
     if phase == 1:
         return "conv3x3_mfma_kernel<1, false" if cout == 16 else f"conv3x3_wino8_kernel<{cout // 16}, false"
     if phase == 2:
@@ -101,11 +113,15 @@ def class_table():
     t = {}
     for layer in range(1, 17):
         for phase in (1, 2, 3):
-            t.setdefault(kernel_class(layer, phase), []).append((layer, phase))
+            cls = kernel_class(layer, phase)
+            if cls is not None:
+                t.setdefault(cls, []).append((layer, phase))
     return t
 
 
-SIDE_BY_SIDE = {"fwd_16x16_256": (1, 1), "dgrad_16x16_256": (1, 2), "wgrad_16x16_256": (1, 3)}   # inbloc.bloc.3
+# inbloc.bloc.3 (16 -> 16 @256^2: forward, and the fused input + weight gradient) and ub3.convbloc.bloc.0 (32 -> 16 @256^2)
+SIDE_BY_SIDE = {"fwd_16x16_256": (1, 1), "bwd16_16x16_256": (1, 2), "fwd_32x16_256": (15, 1), "dgrad_32x16_256": (15, 2),
+                "wgrad_32x16_256": (15, 3)}
 
 
 def dominant_class(stats_file=None):
@@ -361,8 +377,8 @@ def main():
     dom_cls, dom_src = (args.roofline_class, "--roofline-class") if args.roofline_class != "auto" else dominant_class()
     if dom_cls not in table:
         raise SystemExit(f"--roofline-class {dom_cls!r}: not one of {sorted(table)}")
-    selections = []                                   # [(layer, phase)] in slot order
-    if not infer and rank == 0:
+    selections = []                                   # [(layer, phase)] in slot order; on EVERY rank: the extra single-stream
+    if not infer:                                     # steps below contain the gradient all-reduce, a collective
         for lp in (list(table[dom_cls]) if args.dtype == "f32" else []) + list(SIDE_BY_SIDE.values()):
             if lp not in selections:
                 selections.append(lp)
@@ -472,11 +488,12 @@ def main():
         elif args.dtype == "f32":
             def entry(lp):
                 avg_ms, n = ktimes[lp]
-                fl = layer_flops(lp[0]) * batch
+                fl = member_flops(*lp) * batch
                 tf = fl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
                 solo = ksolo.get(lp, 0.0)
                 tf_solo = fl / (solo * 1e-3) / 1e12 if solo > 0 else 0.0
-                return {"layer": LAYER_NAMES[lp[0]], "pass": PHASE_NAMES[lp[1]], "gflop": round(fl / 1e9, 2),
+                return {"layer": LAYER_NAMES[lp[0]], "pass": "dgrad+wgrad (one launch)" if lp[0] in FUSED_BWD16 and lp[1] == 2 else PHASE_NAMES[lp[1]],
+                        "gflop": round(fl / 1e9, 2),
                         "avg_ms": round(avg_ms, 4), "launches_timed": n, "achieved": round(tf, 2),
                         "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                         "solo_ms": round(solo, 4), "solo_frac": round(tf_solo / PEAK_FP32_MFMA_TFLOPS, 4)}
@@ -498,7 +515,8 @@ def main():
                 "solo_ms_per_step": round(cls_solo, 4), "solo_frac": round(cls_tf_solo / PEAK_FP32_MFMA_TFLOPS, 4),
                 "concurrent": ("runs on the second stream beside the input-gradient chain (solo_* = the same launches on one stream)"
                                if "wgrad" in dom_cls else "on the caller's stream; the previous layer's weight gradient may run beside it"),
-                "algorithm": ("winograd F(3x3,2x2)" if "wgrad" in dom_cls else "winograd F(2x2,3x3)") + ": 4/9 of the algorithmic MACs executed",
+                "algorithm": ("winograd F(3x3,2x2)" if "wgrad" in dom_cls else "winograd F(2x2,3x3) + F(3x3,2x2)" if "bwd16" in dom_cls
+                              else "winograd F(2x2,3x3)") + ": 4/9 of the algorithmic MACs executed",
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch, class average (PMC)", "traffic_source": traffic_src,
                 "members": members, "kernels": side, "step": step_obj,
             }

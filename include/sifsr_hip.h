@@ -29,7 +29,7 @@
 #endif
 
 /* ---- introspection (host only, no GPU touched) -------------------------------------------- */
-SIFSR_API int sifsr_abi_version(void);   /* 2 since the Winograd-domain and fused BatchNorm-backward entry points (round 2) */
+SIFSR_API int sifsr_abi_version(void);   /* 3 since round 3 (sifsr_conv3x3_bwd16 added, the split-bf16 entry points removed); 2 = round 2 */
 SIFSR_API int sifsr_num_params(void);   /* 282705 */
 SIFSR_API int sifsr_num_running(void);  /* 1184 = 2 * 592 channels */
 /* out[17][8] = {cin, cout, level, w_off, gamma_off, beta_off, run_off, ch_off}; returns 17 */
@@ -65,8 +65,8 @@ SIFSR_API int sifsr_model_backward_ex(const float* x, const float* dsr, const fl
 
 /* ---- 3x3 convolution pieces (nn.Conv2d(k=3,padding=1,padding_mode='replicate'), model.py:135,138,507) */
 /* OIHW -> MFMA fragment order: wfwd 9*cin*cout floats (forward operand); wdgrad 4*9*cin*cout floats: the
- * transposed+flipped fp32 dgrad operand (n = 9*cin*cout floats) followed by six bf16 packs of n/2 floats each,
- * [fwd hi | dgrad hi | fwd mid | dgrad mid | fwd lo | dgrad lo], with hi + mid + lo = w exactly (hi = bf16(w)). */
+ * transposed+flipped fp32 dgrad operand (n = 9*cin*cout floats) followed by the two bf16 packs of n/2 floats each,
+ * [fwd | dgrad] (config 5), and 2n unused floats (they held the packs of the split-bf16 mode removed in round 3). */
 SIFSR_API int sifsr_pack_conv_weights(const float* w_oihw, int cin, int cout, float* wfwd, float* wdgrad, void* stream);
 /* y = conv(cat([a0, a1], C)), a_i = relu(src_i*scale_i+shift_i) if scale_i != NULL else src_i (NHWC, C_i % 16 == 0;
  * src1 may be NULL).  stat_partials: NULL or [sifsr_conv3x3_stat_blocks()][cout][2] per-workgroup (sum, sumsq) of y. */
@@ -111,15 +111,6 @@ SIFSR_API int sifsr_conv3x3_fwd_bf16(const float* src0, int C0, const float* sca
                                      int cout, float* stat_partials, int B, int H, int W, void* stream);
 SIFSR_API int sifsr_conv3x3_dgrad_bf16(const float* dy, int cout, const float* wdgrad, int cin, float* g0, int C0, float* g1,
                                        int C1, const float* addend, int B, int H, int W, void* stream);
-/* split-bf16 forms ("fp32 on the bf16 matrix cores", compute mode 2 of sifsr_model_*_ex): activations and weights are
- * split exactly into three bf16 terms while staging (x = hi + mid + lo) and six of the nine cross products are
- * accumulated in fp32 (the dropped ones are <= 2^-24 relative): six v_mfma_f32_16x16x32_bf16 per 16 channels of two taps instead
- * of eight v_mfma_f32_16x16x4_f32 at half the cycles each.  Results agree with the fp32 forms to fp32 rounding. */
-SIFSR_API int sifsr_conv3x3_fwd_bf16x3(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1,
-                                       int C1, const float* scale1, const float* shift1, const float* wdgrad, float* y,
-                                       int cout, float* stat_partials, int B, int H, int W, void* stream);
-SIFSR_API int sifsr_conv3x3_dgrad_bf16x3(const float* dy, int cout, const float* wdgrad, int cin, float* g0, int C0, float* g1,
-                                         int C1, const float* addend, int B, int H, int W, void* stream);
 SIFSR_API size_t sifsr_conv3x3_wgrad_scratch_floats(int cin, int cout, int nblk);
 /* dw (OIHW) = sum_pixels dy (x) a_in; deterministic 2-stage reduction through `scratch`. */
 SIFSR_API int sifsr_conv3x3_wgrad(const float* src0, int C0, const float* scale0, const float* shift0,
@@ -140,6 +131,24 @@ SIFSR_API int sifsr_conv3x3_wgrad_wino(const float* src0, int C0, const float* s
                                        const float* src1, int C1, const float* scale1, const float* shift1,
                                        const float* g, const float* y, const float* coef_f, int cout, float* scratch,
                                        int nblk, float* dw, int B, int H, int W, void* stream);
+/* Input gradient AND weight gradient of a 16 -> 16 channel layer (the DoubleConvolution layers at full and half resolution,
+ * model.py:135,138) from ONE read of its operands -- what ModelB_2's backward runs for inbloc.bloc.3, ub3.convbloc.bloc.3 and
+ * db1.resblock.doubleconv.bloc.0/.3 since round 3: the two passes consume the same staged tiles (dL/dy formed from (g, y) while
+ * staging; the forward input a_in = relu(x*x_scale + x_shift), or x itself with x_scale == NULL), so the layer's backward moves
+ * 4 tensors through HBM instead of 7.  Every tensor NHWC with exactly 16 channels; H, W multiples of 16, >= 32 (returns the
+ * shape error otherwise: use sifsr_conv3x3_dgrad_fused / _dgrad_wino + sifsr_conv3x3_wgrad_wino).
+ *   y == coef_f == NULL: g is dL/dy itself (border unused); otherwise g, y, coef_f, border as for sifsr_conv3x3_dgrad_fused.
+ *   gin = conv^T(dL/dy) incl. the replicate-border fold (+ addend);  dw = OIHW weight gradient (16,16,3,3).
+ *   bn_partials != NULL: gin is the gradient w.r.t. relu(bn(bn_y)) of the layer below (raw conv output bn_y, folded BatchNorm
+ *   bn_scale / bn_shift) and its BatchNorm-backward sums are emitted as sifsr_conv3x3_bwd16_stat_rows() rows of [16][2]
+ *   (sum dz, sum dz*y per channel; dz = gin*[bn_y*scale+shift > 0]); add the rows up.  Not together with addend.
+ *   scratch: sifsr_conv3x3_bwd16_scratch_floats() floats (weight-gradient slabs + their float64 sum). */
+SIFSR_API int sifsr_conv3x3_bwd16_stat_rows(int B, int H, int W);
+SIFSR_API size_t sifsr_conv3x3_bwd16_scratch_floats(int B, int H, int W);
+SIFSR_API int sifsr_conv3x3_bwd16(const float* x, const float* x_scale, const float* x_shift, const float* g, const float* y,
+                                  const float* coef_f, float* border, const float* wdgrad, const float* wwd, float* gin,
+                                  const float* addend, const float* bn_y, const float* bn_scale, const float* bn_shift,
+                                  float* bn_partials, float* scratch, float* dw, int B, int H, int W, void* stream);
 /* bf16-operand form of the weight gradient (BASELINE.json config 5): the staged x and dy are rounded to bf16 when
  * read from LDS and contracted 16 pixels at a time with v_mfma_f32_16x16x16_bf16; fp32 accumulation and slabs. */
 SIFSR_API int sifsr_conv3x3_wgrad_bf16(const float* src0, int C0, const float* scale0, const float* shift0,

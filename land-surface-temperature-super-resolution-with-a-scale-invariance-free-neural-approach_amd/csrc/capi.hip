@@ -10,7 +10,7 @@ static ConvSrc mk_src(const float* p, int C, const float* sc, const float* sh) {
   return s;
 }
 
-int sifsr_abi_version(void) { return 2; }   // 2: Winograd-domain entry points, fused BatchNorm-backward forms (round 2)
+int sifsr_abi_version(void) { return 3; }   // 2: Winograd-domain entry points, fused BatchNorm-backward forms (round 2); 3: sifsr_conv3x3_bwd16, split-bf16 entry points removed (round 3)
 int sifsr_num_params(void) { return sifsr_net().total_params; }
 int sifsr_num_running(void) { return sifsr_net().total_running; }
 int sifsr_layer_table(int* out, int capacity_rows) {
@@ -164,7 +164,7 @@ int sifsr_conv3x3_dgrad_fused(const float* g, const float* y, const float* coef_
 }
 
 // bf16-operand forms (config 5): both bf16 packs live in the second half of the `wdgrad` buffer written by
-// sifsr_pack_conv_weights ([fp32 dgrad pack n | fwd hi n/2 | dgrad hi n/2 | fwd mid | dgrad mid | fwd lo | dgrad lo], n = 9*cin*cout floats)
+// sifsr_pack_conv_weights ([fp32 dgrad pack n | fwd bf16 n/2 | dgrad bf16 n/2 | unused 2n], n = 9*cin*cout floats)
 static int conv3x3_fwd_lowp(int mode, const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
                             const float* scale1, const float* shift1, const float* wdgrad, float* y, int cout,
                             float* stat_partials, int B, int H, int W, void* stream) {
@@ -185,11 +185,6 @@ int sifsr_conv3x3_fwd_bf16(const float* src0, int C0, const float* scale0, const
                            float* stat_partials, int B, int H, int W, void* stream) {
   return conv3x3_fwd_lowp(1, src0, C0, scale0, shift0, src1, C1, scale1, shift1, wdgrad, y, cout, stat_partials, B, H, W, stream);
 }
-int sifsr_conv3x3_fwd_bf16x3(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
-                             const float* scale1, const float* shift1, const float* wdgrad, float* y, int cout,
-                             float* stat_partials, int B, int H, int W, void* stream) {
-  return conv3x3_fwd_lowp(2, src0, C0, scale0, shift0, src1, C1, scale1, shift1, wdgrad, y, cout, stat_partials, B, H, W, stream);
-}
 static int conv3x3_dgrad_lowp(int mode, const float* dy, int cout, const float* wdgrad, int cin, float* g0, int C0, float* g1, int C1,
                               const float* addend, int B, int H, int W, void* stream) {
   if (cout % 16 || cin % 16 || C0 % 16 || (g1 && (C1 % 16 || C0 + C1 != cin)) || (!g1 && C0 != cin) || (addend && g1))
@@ -204,18 +199,13 @@ static int conv3x3_dgrad_lowp(int mode, const float* dy, int cout, const float* 
   a.B = B; a.H = H; a.W = W; a.NQ = cout / 16;
   int rc = launch_conv3x3_mfma(a, cin, 1, S(stream));
   if (rc) return rc;
-  // border fold: bf16 mode rounds its operands like the main kernel; the split mode is exact, so plain fp32 there
-  return launch_dgrad_border_fix(dy, cout, wdgrad, cin, g0, C0, C0, g1 ? g1 : g0, g1 ? C1 : C0, B, H, W, S(stream), mode == 1 ? 1 : 0);
+  // border fold: rounds its operands like the main kernel
+  return launch_dgrad_border_fix(dy, cout, wdgrad, cin, g0, C0, C0, g1 ? g1 : g0, g1 ? C1 : C0, B, H, W, S(stream), mode);
 }
 int sifsr_conv3x3_dgrad_bf16(const float* dy, int cout, const float* wdgrad, int cin, float* g0, int C0, float* g1, int C1,
                              const float* addend, int B, int H, int W, void* stream) {
   return conv3x3_dgrad_lowp(1, dy, cout, wdgrad, cin, g0, C0, g1, C1, addend, B, H, W, stream);
 }
-int sifsr_conv3x3_dgrad_bf16x3(const float* dy, int cout, const float* wdgrad, int cin, float* g0, int C0, float* g1, int C1,
-                               const float* addend, int B, int H, int W, void* stream) {
-  return conv3x3_dgrad_lowp(2, dy, cout, wdgrad, cin, g0, C0, g1, C1, addend, B, H, W, stream);
-}
-
 size_t sifsr_conv3x3_wgrad_scratch_floats(int cin, int cout, int nblk) { return (size_t)nblk * wgrad_slab_floats(cin, cout); }
 
 int sifsr_conv3x3_wgrad(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
@@ -275,6 +265,38 @@ int sifsr_conv3x3_wgrad_wino(const float* src0, int C0, const float* scale0, con
   WgradReduceJob j;
   j.slab_off = 0; j.nblk = nblk; j.cin = cin; j.cout = cout; j.nbi_chunk = wgrad_wino_nbi_chunk(a, cin); j.w_off = 0;
   return launch_wgrad_wino_finish(scratch, &j, 1, reinterpret_cast<double*>(scratch + (size_t)nblk * 16 * cin * cout), dw, S(stream));
+}
+
+// Input gradient AND weight gradient of a 16 -> 16 channel layer from one read of its operands (conv_bwd16.hip).
+int sifsr_conv3x3_bwd16_stat_rows(int B, int H, int W) {
+  return conv3x3_bwd16_applies(B, H, W) ? conv3x3_bwd16_grid(B, H, W) + dgrad_border_waves(B, H, W, 16) : 0;
+}
+size_t sifsr_conv3x3_bwd16_scratch_floats(int B, int H, int W) {
+  return conv3x3_bwd16_applies(B, H, W) ? ((size_t)4 * conv3x3_bwd16_grid(B, H, W) + 2) * 16 * 256 : 0;
+}
+int sifsr_conv3x3_bwd16(const float* x, const float* x_scale, const float* x_shift, const float* g, const float* y,
+                        const float* coef_f, float* border, const float* wdgrad, const float* wwd, float* gin,
+                        const float* addend, const float* bn_y, const float* bn_scale, const float* bn_shift,
+                        float* bn_partials, float* scratch, float* dw, int B, int H, int W, void* stream) {
+  if (!conv3x3_bwd16_applies(B, H, W)) return SIFSR_ERR_SHAPE;
+  if (!x || !g || !wdgrad || !wwd || !gin || !scratch || !dw) return SIFSR_ERR_ARG;
+  if ((y != nullptr) != (coef_f != nullptr) || (y != nullptr && !border)) return SIFSR_ERR_ARG;
+  if (bn_partials != nullptr && (!bn_y || !bn_scale || !bn_shift || addend != nullptr)) return SIFSR_ERR_ARG;
+  const int grid = conv3x3_bwd16_grid(B, H, W);
+  Bwd16Args a;
+  a.x = x; a.x_scale = x_scale; a.x_shift = x_shift; a.g = g; a.y = y; a.coef = coef_f; a.dy_border = y ? border : nullptr;
+  a.wpack_wino = wwd; a.gin = gin; a.addend = addend;
+  if (bn_partials != nullptr) { a.bn_y = bn_y; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.stat_partials = bn_partials; }
+  a.slabs = scratch; a.B = B; a.H = H; a.W = W;
+  int rc = launch_conv3x3_bwd16(a, S(stream));
+  if (rc) return rc;
+  rc = launch_dgrad_border_fix(y ? border : g, 16, wdgrad, 16, gin, 16, 16, gin, 16, B, H, W, S(stream), 0,
+                               bn_partials ? bn_y : nullptr, bn_partials ? bn_scale : nullptr, bn_partials ? bn_shift : nullptr,
+                               bn_partials ? bn_partials + (size_t)grid * 32 : nullptr);
+  if (rc) return rc;
+  WgradReduceJob j;
+  j.slab_off = 0; j.nblk = 4 * grid; j.cin = 16; j.cout = 16; j.nbi_chunk = 1; j.w_off = 0;
+  return launch_wgrad_wino_finish(scratch, &j, 1, reinterpret_cast<double*>(scratch + (size_t)4 * grid * 16 * 256), dw, S(stream));
 }
 
 // bf16-operand form (config 5): x and dy rounded to bf16 when read from LDS, fp32 accumulation

@@ -59,8 +59,12 @@ static __device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh
 //      padded by the compiler, but it reschedules the transforms and the 64-channel Winograd kernels go from 255 registers to
 //      256 + 85..136 spilled -- kept for A/B only.
 //   3  two scalar adds per pair (round-2 A/B: 7-8 % slower per layer beside v_mfma_f32_16x16x4_f32).
+// Measured on one MI355X, same device, interleaved (round 3, whole SR2 step at batch 64): mode 0 9,905 patches/s, mode 1 9,570
+// (-3.4 %: the two wait states after each of ~120 packed adds per work item are not hidden), mode 2 8,645 (-12.7 %: spills in
+// the MFMA loops).  Mode 0 ships; the lint covers fall-through order AND every branch edge (loop back-edges included) of the
+// exact objects that are linked into the library.
 #ifndef SIFSR_PK_MODE
-#define SIFSR_PK_MODE 1
+#define SIFSR_PK_MODE 0
 #endif
 #if SIFSR_PK_MODE == 3
 static __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return (f32x2){a[0] - b[0], a[1] - b[1]}; }

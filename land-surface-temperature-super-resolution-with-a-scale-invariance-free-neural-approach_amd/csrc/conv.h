@@ -89,6 +89,31 @@ int wgrad_wino_nbi_chunk(const WgradArgs& a, int cin);   // its Cin chunking (a 
 int launch_conv3x3_wgrad_wino(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s);
 int launch_wgrad_wino_finish(const float* ws, const WgradReduceJob* jobs, int njobs, double* mbuf, float* grads, hipStream_t s);
 
+// Input gradient AND weight gradient of a 16 -> 16 channel layer from one read of its operands (conv_bwd16.hip): H, W multiples
+// of 16, every tensor NHWC with exactly 16 channels.
+struct Bwd16Args {
+  const float* x;                  // the layer's forward input: a raw conv output (x_scale / x_shift = the folded BatchNorm of the
+  const float* x_scale = nullptr;  //   layer below, relu(x * scale + shift) applied while staging) or, with nullptr, a stored tensor
+  const float* x_shift = nullptr;
+  const float* g;                  // dL/d relu(bn(y)) of this layer -- or dL/dy itself when y == nullptr
+  const float* y = nullptr;        // this layer's raw conv output: dL/dy is formed while staging (bn_bwd4) ...
+  const float* coef = nullptr;     // ... from [sc | sh | k1 | k0], 16 floats each (bn_bwd_finalize*)
+  float* dy_border = nullptr;      // with y: dL/dy of the image-border pixels goes here (NHWC indexing) for the border-fold kernel
+  const float* wpack_wino;         // Winograd-domain input-gradient weights of the layer (pack_wino_kernel, wwd), 16 * 256 floats
+  float* gin;                      // out: gradient w.r.t. the layer's input (zero-padded part; the border fold is a separate kernel)
+  const float* addend = nullptr;   // optional tensor added to gin (residual gradient)
+  const float* bn_y = nullptr;     // optional: raw conv output of the layer BELOW + its (scale, shift): the epilogue also emits that
+  const float* bn_scale = nullptr; //   layer's BatchNorm-backward sums (sum dz, sum dz * y per channel) ...
+  const float* bn_shift = nullptr;
+  float* stat_partials = nullptr;  // ... as [conv3x3_bwd16_grid()][16][2]
+  float* slabs;                    // out: 4 * conv3x3_bwd16_grid() weight-gradient slabs of 16 * 256 floats (Winograd domain,
+                                   //   the layout of conv_wgrad_wino.hip; reduce with launch_wgrad_wino_finish, nblk = 4 * grid)
+  int B, H, W;
+};
+bool conv3x3_bwd16_applies(int B, int H, int W);
+int conv3x3_bwd16_grid(int B, int H, int W);           // workgroups launched = stat_partials rows; 4 slabs each
+int launch_conv3x3_bwd16(const Bwd16Args& a, hipStream_t s);
+
 // dgrad: replicate-padding adjoint fold for the border pixels (adds to g_in).  wdg_layer = the layer's
 // dgrad weight pack [fragment order | tap-major] written by pack_weights.
 int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, int Cin, float* g0, int C0,

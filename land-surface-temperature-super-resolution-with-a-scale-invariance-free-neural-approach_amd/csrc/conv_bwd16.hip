@@ -1,0 +1,394 @@
+// Input gradient AND weight gradient of a 16 -> 16 channel replicate-padded 3x3 convolution from ONE read of its operands
+// (nn.Conv2d backward, model.py:135,138 -- the DoubleConvolution layers at full and half resolution: inbloc.bloc.3,
+// ub3.convbloc.bloc.3, db1.resblock.doubleconv.bloc.0/.3).
+//
+// Why: with 4/9 of the matrix work gone (Winograd) these layers are HBM-bound in every pass, and the separate kernels read the
+// same tensors again and again -- per layer the input gradient reads (g, y, y_below) and writes g_below (4 tensors), the weight
+// gradient reads (y_below, g, y) once more (3 tensors).  Both passes consume exactly the same staged data:
+//   dL/dy tile (18x18 halo, formed from (g, y) by the BatchNorm+ReLU backward while staging, never stored)  -> dgrad B operand
+//   dL/dy tile (16x16 core) and a_in = relu(bn(y_below)) tile (18x18 halo)                                 -> wgrad operands
+// so this kernel stages them once (4 tensors of HBM traffic instead of 7) and splits the matrix work by WAVE ROLE:
+//   waves 0-3  input gradient,  Winograd F(2x2,3x3): the consumer of conv_mfma.hip (lane = (patch, cout quad); 16 ds_read_b128 of
+//              the patch's 4x4 window, input transform in registers, 64 MFMAs per 16-patch group, output transform per xi-row),
+//              transform-domain weights in LDS; epilogue = NHWC stores (+ residual addend) and the BatchNorm-backward sums of the
+//              layer below (its y requested before the MFMAs);
+//   waves 4-7  weight gradient, Winograd F(3x3,2x2): the per-lane register transforms of conv_wgrad_wino.hip (lane = (channel,
+//              patch of a 4-patch k-step); 2 + 8 ds_read_b64 from channel planes, 16 MFMAs per k-step, 4 k-steps per wave and
+//              tile), accumulators live across all tiles, one slab per wave at the end.
+// One of each role per SIMD: the two MFMA streams (64 MFMAs per wave and tile each) interleave on the matrix pipe and each
+// role's transform / epilogue instructions issue under the other's MFMAs.  All eight waves stage: thread = (channel quad,
+// 3 of the 324 halo pixels), the next tile's 9 float4 loads in flight during the contraction, LDS double-buffered -> ONE barrier
+// per tile.  The replicate-border fold of the input gradient stays the separate kernel (dgrad_border_kernel).
+#include "conv.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int WPITCH = 20, WHALF = 10, WPLANE = 364;   // dgrad operand layout, as conv_mfma.hip (even / odd columns split)
+constexpr int DPS = 260;                               // wgrad dy channel-plane stride (floats): >= 256, = 4 (mod 64)
+constexpr int XPS = 324;                               // wgrad input channel-plane stride: 18*18 = 324 = 4 (mod 64)
+constexpr int XPW = 18;
+constexpr int DYQ_F4 = 4 * WPLANE;                     // float4 slots of the dgrad layout
+constexpr int DYP_F = 16 * DPS, XP_F = 16 * XPS;       // floats
+constexpr unsigned OOB = 0xFFFFFF00u;
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4b;
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+static __device__ __forceinline__ float4 bl4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4b v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+static __device__ __forceinline__ void bs4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 v) {
+  u32x4b u;
+  u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, (int)soff, 0);
+}
+static __device__ __forceinline__ int xslot(int i) { return (i >> 2) + 4 * (i & 3); }
+
+template <bool DYF>
+__global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a, const int ntiles, const int lgx, const int lgy) {
+  __shared__ float4 dyq[2][DYQ_F4];                       // dL/dy halo, [cout quad][pixel (even | odd columns)][4]
+  __shared__ __align__(16) float dyp[2][DYP_F + 16];      // dL/dy core, channel planes
+  __shared__ __align__(16) float xp[2][XP_F + 16];        // a_in halo, channel planes
+  __shared__ float4 wlds[16 * 64];                        // transform-domain dgrad weights, [xi][lane]
+  __shared__ float red[4][16][2];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_amdgcn_s_setprio(2);                          // chain kernel: above a weight gradient of another layer on the second stream
+  const int H = a.H, W = a.W;
+  const int tiles_x = W / 16, tiles_y = H / 16;           // H, W multiples of 16 (checked by the launcher)
+  const unsigned npix = (unsigned)a.B * (unsigned)H * (unsigned)W;
+
+  // ---- persistent XCD-aware tile walk (conv_mfma.hip)
+  const int G = gridDim.x;
+  const bool xcd_map = (G % 8 == 0) && (ntiles % 8 == 0);
+  const int t_lo = xcd_map ? (blockIdx.x % 8) * (ntiles / 8) : 0;
+  const int t_hi = xcd_map ? t_lo + ntiles / 8 : ntiles;
+  const int t_step = xcd_map ? G / 8 : G;
+  const int t_first = t_lo + (xcd_map ? blockIdx.x / 8 : blockIdx.x);
+  auto tile_pos = [&](int tt, int& tb, int& txi, int& tyi) {
+    if (lgx >= 0) { tyi = (tt >> lgx) & (tiles_y - 1); tb = tt >> (lgx + lgy); txi = (tt + tyi + tb) & (tiles_x - 1); }
+    else { txi = tt % tiles_x; const int r = tt / tiles_x; tyi = r % tiles_y; tb = r / tiles_y; }
+  };
+
+  for (int i = tid; i < 16 * 64; i += 512) wlds[i] = ld4(a.wpack_wino + 4 * (size_t)i);
+
+  const __amdgpu_buffer_rsrc_t rg = mk_rsrc(a.g, npix * 64u);
+  const __amdgpu_buffer_rsrc_t ry = mk_rsrc(DYF ? a.y : a.g, npix * 64u);
+  const __amdgpu_buffer_rsrc_t rx = mk_rsrc(a.x, npix * 64u);
+  const __amdgpu_buffer_rsrc_t rbd = mk_rsrc(DYF && a.dy_border ? a.dy_border : const_cast<float*>(a.g), npix * 64u);
+
+  // ---- staging map: thread -> (channel quad cg, halo pixels pslot + 128 it, it < 3)
+  const int cg = tid & 3, pslot = tid >> 2;
+  int spy[3], spx[3];
+  unsigned rel[3];                                        // byte offset of the slot relative to the halo origin (interior tiles)
+  int lq[3], lp[3], lx[3];                                // LDS indices: dgrad layout (float4), dy plane (float, -1: not core), x plane
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    int p = pslot + 128 * it;
+    if (p >= 324) p = 323;                                // lanes past the tile re-load the last pixel and store nothing
+    spy[it] = p / 18; spx[it] = p - spy[it] * 18;
+    rel[it] = (unsigned)(spy[it] * W + spx[it]) * 64u + (unsigned)cg * 16u;
+    lq[it] = cg * WPLANE + spy[it] * WPITCH + (spx[it] & 1) * WHALF + (spx[it] >> 1);
+    const bool core = spy[it] >= 1 && spy[it] <= 16 && spx[it] >= 1 && spx[it] <= 16;
+    lp[it] = core ? cg * DPS + (spy[it] - 1) * 16 + (spx[it] - 1) : -1;
+    lx[it] = cg * XPS + p;
+  }
+  const bool slot2 = pslot + 256 < 324;
+  float4 csc = make_float4(0.f, 0.f, 0.f, 0.f), csh = csc, ck1 = csc, ck0 = csc;
+  if (DYF) { csc = ld4(a.coef + 4 * cg); csh = ld4(a.coef + 16 + 4 * cg); ck1 = ld4(a.coef + 32 + 4 * cg); ck0 = ld4(a.coef + 48 + 4 * cg); }
+  const bool xraw = a.x_scale == nullptr;
+  float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!xraw) { xsc = ld4(a.x_scale + 4 * cg); xsh = ld4(a.x_shift + 4 * cg); }
+
+  float4 pg[3], py[DYF ? 3 : 1], px_[3];                 // the tile in flight
+  int st_b = 0, st_tx = 0, st_ty = 0;                     // ... and its position
+  auto issue = [&](int tt) {
+    tile_pos(tt, st_b, st_tx, st_ty);
+    const int x0 = st_tx * 16 - 1, y0 = st_ty * 16 - 1;
+    const bool interior = st_tx > 0 && st_ty > 0 && st_tx + 1 < tiles_x && st_ty + 1 < tiles_y;
+    if (interior) {
+      const unsigned soff = (unsigned)((st_b * H + y0) * W + x0) * 64u;
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        pg[it] = bl4(rg, rel[it], soff);
+        if (DYF) py[it] = bl4(ry, rel[it], soff);
+        px_[it] = bl4(rx, rel[it], soff);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        const int gy = y0 + spy[it], gx = x0 + spx[it];
+        const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const unsigned pc = (unsigned)((st_b * H + clampi(gy, 0, H - 1)) * W + clampi(gx, 0, W - 1)) * 64u + (unsigned)cg * 16u;
+        pg[it] = bl4(rg, inside ? pc : OOB, 0u);          // zero padding of dL/dy
+        if (DYF) py[it] = bl4(ry, inside ? pc : OOB, 0u);
+        px_[it] = bl4(rx, pc, 0u);                        // replicate padding of the forward input
+      }
+    }
+  };
+  auto write_stage = [&](int buf) {
+    const int x0 = st_tx * 16 - 1, y0 = st_ty * 16 - 1;
+    const bool interior = st_tx > 0 && st_ty > 0 && st_tx + 1 < tiles_x && st_ty + 1 < tiles_y;
+    float4* const Q = dyq[buf];
+    float* const P = dyp[buf];
+    float* const X = xp[buf];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      if (it == 2 && !slot2) continue;
+      float4 v = pg[it];
+      if (DYF) {
+        v = bn_bwd4(v, py[it], csc, csh, ck1, ck0);
+        if (!interior) {
+          const int gy = y0 + spy[it], gx = x0 + spx[it];
+          const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+          if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);   // bn_bwd4 of the zeros that were loaded is not 0
+          const bool edge = gy == 0 || gy == H - 1 || gx == 0 || gx == W - 1;
+          if (a.dy_border != nullptr && inside && lp[it] >= 0 && edge)   // dL/dy on the image border, for the border-fold kernel
+            bs4(rbd, (unsigned)((st_b * H + gy) * W + gx) * 64u + (unsigned)cg * 16u, 0u, v);
+        }
+      }
+      Q[lq[it]] = v;
+      if (lp[it] >= 0) {
+        float* d = P + lp[it];
+        d[0] = v.x; d[4 * DPS] = v.y; d[8 * DPS] = v.z; d[12 * DPS] = v.w;   // channel 4 cg + r -> plane cg + 4 r
+      }
+      float4 xv = px_[it];
+      if (!xraw) xv = bn_relu4(xv, xsc, xsh);
+      float* e = X + lx[it];
+      e[0] = xv.x; e[4 * XPS] = xv.y; e[8 * XPS] = xv.z; e[12 * XPS] = xv.w;
+    }
+  };
+
+  const bool dgrad_role = wave8 < 4;
+  const int wave = wave8 & 3;
+  const int kq = lane >> 4, i16 = lane & 15;
+  // ---- input-gradient state
+  const int pxp = lane & 7, pyl = (lane >> 3) & 1;
+  const int g0 = wave * 4;
+  const int lbase = kq * WPLANE + (g0 + 2 * pyl) * WPITCH + pxp;
+  const __amdgpu_buffer_rsrc_t rd = mk_rsrc(a.gin, npix * 64u);
+  const __amdgpu_buffer_rsrc_t rad = mk_rsrc(a.addend ? a.addend : a.gin, npix * 64u);
+  const bool bn_stats = a.bn_y != nullptr;
+  const __amdgpu_buffer_rsrc_t rby = mk_rsrc(bn_stats ? a.bn_y : a.gin, npix * 64u);
+  float4 bsc = make_float4(0.f, 0.f, 0.f, 0.f), bsh = bsc;
+  if (bn_stats) { bsc = ld4(a.bn_scale + 4 * kq); bsh = ld4(a.bn_shift + 4 * kq); }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  // ---- weight-gradient state (the accumulators are declared in the weight-gradient branch)
+  const int pa_off = xslot(i16) * DPS + 2 * kq;           // my dy plane, my patch of a k-step (kq = patch of the 4)
+  const int pb_off = xslot(i16) * XPS + 2 * kq;
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto lo2 = [](f32x4 v) { return (f32x2){v[0], v[1]}; };
+  auto hi2 = [](f32x4 v) { return (f32x2){v[2], v[3]}; };
+  auto acc2 = [](f32x4& y, f32x2 l, f32x2 h, bool minus) {
+    const f32x2 yl = minus ? pk_sub((f32x2){y[0], y[1]}, l) : pk_add((f32x2){y[0], y[1]}, l);
+    const f32x2 yh = minus ? pk_sub((f32x2){y[2], y[3]}, h) : pk_add((f32x2){y[2], y[3]}, h);
+    y = (f32x4){yl[0], yl[1], yh[0], yh[1]};
+  };
+
+  // The tile loop, instantiated once per role (two loops, not one loop with a role branch inside: the weight-gradient
+  // accumulators are then live only in the weight-gradient waves' code and the input-gradient waves' transforms do not spill).
+  // Both roles execute exactly one barrier per tile, so the workgroup's barrier counts match.
+  auto tile_loop = [&](auto&& contract) {
+    int t = t_first, buf = 0;
+    if (t < t_hi) issue(t);
+    __syncthreads();                                      // wlds
+    while (t < t_hi) {
+      write_stage(buf);
+      const int cb = st_b, txi = st_tx, tyi = st_ty;      // the tile being contracted
+      const int t_next = t + t_step;
+      if (t_next < t_hi) issue(t_next);                   // in flight during the contraction below
+      __syncthreads();                                    // tile staged (and everybody is past the previous use of the other buffer)
+      contract(buf, cb, txi, tyi);
+      t = t_next;
+      buf ^= 1;
+    }
+  };
+
+  if (dgrad_role) {
+    tile_loop([&](const int buf, const int cb, const int txi, const int tyi) {
+      // ======================= input gradient: Winograd F(2x2,3x3), one 16-patch group (4 tile rows) per wave =======================
+      float4 yq[4];
+      if (bn_stats) {
+        const int y0_ = tyi * 16 + g0 + 2 * pyl, x0_ = txi * 16 + 2 * pxp;
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+          yq[o] = bl4(rby, (unsigned)((cb * H + y0_ + (o >> 1)) * W + x0_ + (o & 1)) * 64u + (unsigned)kq * 16u, 0u);
+      }
+      f32x2 dl[4][4], dh[4][4];
+      const float4* Lg = dyq[buf] + lbase;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float4 v0 = Lg[r * WPITCH], v1 = Lg[r * WPITCH + WHALF], v2 = Lg[r * WPITCH + 1], v3 = Lg[r * WPITCH + WHALF + 1];
+        dl[r][0] = (f32x2){v0.x, v0.y}; dh[r][0] = (f32x2){v0.z, v0.w};
+        dl[r][1] = (f32x2){v1.x, v1.y}; dh[r][1] = (f32x2){v1.z, v1.w};
+        dl[r][2] = (f32x2){v2.x, v2.y}; dh[r][2] = (f32x2){v2.z, v2.w};
+        dl[r][3] = (f32x2){v3.x, v3.y}; dh[r][3] = (f32x2){v3.z, v3.w};
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {     // rows of B^T d: [d0 - d2, d1 + d2, d2 - d1, d1 - d3]
+        const f32x2 l0 = pk_sub(dl[0][c], dl[2][c]), l1 = pk_add(dl[1][c], dl[2][c]), l2 = pk_sub(dl[2][c], dl[1][c]), l3 = pk_sub(dl[1][c], dl[3][c]);
+        const f32x2 h0 = pk_sub(dh[0][c], dh[2][c]), h1 = pk_add(dh[1][c], dh[2][c]), h2 = pk_sub(dh[2][c], dh[1][c]), h3 = pk_sub(dh[1][c], dh[3][c]);
+        dl[0][c] = l0; dl[1][c] = l1; dl[2][c] = l2; dl[3][c] = l3;
+        dh[0][c] = h0; dh[1][c] = h1; dh[2][c] = h2; dh[3][c] = h3;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {     // columns, same pattern
+        const f32x2 l0 = pk_sub(dl[r][0], dl[r][2]), l1 = pk_add(dl[r][1], dl[r][2]), l2 = pk_sub(dl[r][2], dl[r][1]), l3 = pk_sub(dl[r][1], dl[r][3]);
+        const f32x2 h0 = pk_sub(dh[r][0], dh[r][2]), h1 = pk_add(dh[r][1], dh[r][2]), h2 = pk_sub(dh[r][2], dh[r][1]), h3 = pk_sub(dh[r][1], dh[r][3]);
+        dl[r][0] = l0; dl[r][1] = l1; dl[r][2] = l2; dl[r][3] = l3;
+        dh[r][0] = h0; dh[r][1] = h1; dh[r][2] = h2; dh[r][3] = h3;
+      }
+      f32x4 Y[2][2] = {{zero4, zero4}, {zero4, zero4}};
+#pragma unroll
+      for (int ar = 0; ar < 4; ++ar) {
+        f32x4 Mc[4];
+        float4 wr[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) wr[b] = wlds[(4 * ar + b) * 64 + lane];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Mc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[b].x, dl[ar][b][0], zero4, 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Mc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[b].y, dl[ar][b][1], Mc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Mc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[b].z, dh[ar][b][0], Mc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Mc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[b].w, dh[ar][b][1], Mc[b], 0, 0, 0);
+        // t = M A: t0 = M0 + M1 + M2, t1 = M1 - (M2 + M3); the first reads of fresh MFMA results are compiler-visible adds
+        // (it pads the matrix-pipe -> VALU hazard for those, not for inline assembly -- conv_mfma.hip)
+        const f32x4 t0 = Mc[0] + Mc[1] + Mc[2], u = Mc[2] + Mc[3];
+        const f32x2 t0l = lo2(t0), t0h = hi2(t0);
+        const f32x2 t1l = pk_sub(lo2(Mc[1]), lo2(u)), t1h = pk_sub(hi2(Mc[1]), hi2(u));
+        if (ar <= 2) { acc2(Y[0][0], t0l, t0h, false); acc2(Y[0][1], t1l, t1h, false); }
+        if (ar == 1) { acc2(Y[1][0], t0l, t0h, false); acc2(Y[1][1], t1l, t1h, false); }
+        if (ar >= 2) { acc2(Y[1][0], t0l, t0h, true); acc2(Y[1][1], t1l, t1h, true); }
+      }
+      // ---- epilogue: the lane's 2x2 output pixels x 4 input channels
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int oy = o >> 1, ox = o & 1;
+        const int yy = tyi * 16 + g0 + 2 * pyl + oy, xx = txi * 16 + 2 * pxp + ox;
+        f32x4 v = Y[oy][ox];
+        const unsigned pixo = (unsigned)((cb * H + yy) * W + xx) * 64u + (unsigned)kq * 16u;
+        if (a.addend != nullptr) {
+          const float4 ad = bl4(rad, pixo, 0u);
+          v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+        }
+        bs4(rd, pixo, 0u, make_float4(v[0], v[1], v[2], v[3]));
+        if (bn_stats) {   // dz = g_in * [y_below * scale + shift > 0]; sum dz, sum dz * y_below
+          const float yy4[4] = {yq[o].x, yq[o].y, yq[o].z, yq[o].w};
+          const float scv[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, shv[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dz = fmaf(yy4[r], scv[r], shv[r]) > 0.f ? v[r] : 0.f;
+            s1[r] += dz; s2[r] = fmaf(dz, yy4[r], s2[r]);
+          }
+        }
+      }
+    });
+  } else {
+    f32x4 acc[16];
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tile_loop([&](const int buf, const int cb, const int txi, const int tyi) {
+      (void)cb; (void)txi; (void)tyi;
+      // ======================= weight gradient: Winograd F(3x3,2x2), 4 k-steps (of 4 patches) per wave =======================
+      const float* const pa = dyp[buf] + pa_off;
+      const float* const pb = xp[buf] + pb_off;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int h = wave + 4 * j;                       // k-step: patch row h >> 1 (0..7), patch columns 4 (h & 1) + (0..3)
+        const int pr = h >> 1, pcb = 4 * (h & 1);
+        float ug[16], vv[16];
+        {
+          const float* q = pa + (2 * pr) * 16 + 2 * pcb;
+          const f32x2 d0 = *reinterpret_cast<const f32x2*>(q), d1 = *reinterpret_cast<const f32x2*>(q + 16);
+          const f32x2 r1 = pk_add(d0, d1), r2 = pk_sub(d0, d1);               // rows of G g: [g0, g0 + g1, g0 - g1, g1]
+          const f32x2 rows[4] = {d0, r1, r2, d1};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {                                       // columns: (x, y) -> [x, x + y, x - y, y]
+            ug[4 * u + 0] = rows[u][0]; ug[4 * u + 1] = rows[u][0] + rows[u][1];
+            ug[4 * u + 2] = rows[u][0] - rows[u][1]; ug[4 * u + 3] = rows[u][1];
+          }
+        }
+        {
+          const float* q = pb + (2 * pr) * XPW + 2 * pcb;
+          f32x2 wl[4], wh[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { wl[u] = *reinterpret_cast<const f32x2*>(q + u * XPW); wh[u] = *reinterpret_cast<const f32x2*>(q + u * XPW + 2); }
+          // rows: [d0 - d2, d1 + d2, d2 - d1, d3 - d1] on both pixel pairs
+          const f32x2 rl[4] = {pk_sub(wl[0], wl[2]), pk_add(wl[1], wl[2]), pk_sub(wl[2], wl[1]), pk_sub(wl[3], wl[1])};
+          const f32x2 rh[4] = {pk_sub(wh[0], wh[2]), pk_add(wh[1], wh[2]), pk_sub(wh[2], wh[1]), pk_sub(wh[3], wh[1])};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {                                       // columns: same pattern on (x0, x1 | x2, x3)
+            vv[4 * u + 0] = rl[u][0] - rh[u][0]; vv[4 * u + 1] = rl[u][1] + rh[u][0];
+            vv[4 * u + 2] = rh[u][0] - rl[u][1]; vv[4 * u + 3] = rh[u][1] - rl[u][1];
+          }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ug[tt], vv[tt], acc[tt], 0, 0, 0);
+      }
+    });
+    // ---- weight-gradient slabs: one per weight-gradient wave, [xi][lane][4] (the layout of conv_wgrad_wino.hip for one block pair)
+    float* slab = a.slabs + ((size_t)blockIdx.x * 4 + wave) * (16 * 256);
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) st4(slab + tt * 256 + lane * 4, make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]));
+  }
+  // ---- BatchNorm-backward partials of the layer below: one row per workgroup
+  if (a.stat_partials != nullptr) {
+    if (dgrad_role) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float u = s1[r], v = s2[r];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
+        if (i16 == 0) { red[wave][4 * kq + r][0] = u; red[wave][4 * kq + r][1] = v; }
+      }
+    }
+    __syncthreads();
+    if (tid < 16) {
+      float u = 0.f, v = 0.f;
+      for (int w = 0; w < 4; ++w) { u += red[w][tid][0]; v += red[w][tid][1]; }
+      float* o = a.stat_partials + ((size_t)blockIdx.x * 16 + tid) * 2;
+      o[0] = u; o[1] = v;
+    }
+  }
+}
+
+}  // namespace
+
+bool conv3x3_bwd16_applies(int B, int H, int W) {
+  static const int off = getenv("SIFSR_NO_BWD16") ? atoi(getenv("SIFSR_NO_BWD16")) : 0;   // 1: separate input- / weight-gradient kernels (A/B)
+  return !off && B >= 1 && H >= 32 && W >= 32 && H % 16 == 0 && W % 16 == 0 && (size_t)B * H * W * 64 < ((size_t)1 << 32) - 4096;
+}
+
+int conv3x3_bwd16_grid(int B, int H, int W) {
+  const int ntiles = B * (H / 16) * (W / 16);
+  static const int dbg = getenv("SIFSR_DBG_BWD16_GRID") ? atoi(getenv("SIFSR_DBG_BWD16_GRID")) : 256;   // one workgroup per CU
+  if (ntiles <= dbg) return ntiles;
+  const int rounds = (ntiles + dbg - 1) / dbg;
+  int g = (ntiles + rounds - 1) / rounds;
+  g = (g + 7) & ~7;
+  return g < ntiles ? g : ntiles;
+}
+
+int launch_conv3x3_bwd16(const Bwd16Args& a, hipStream_t s) {
+  if (!conv3x3_bwd16_applies(a.B, a.H, a.W)) return SIFSR_ERR_SHAPE;
+  if (!a.x || !a.g || !a.wpack_wino || !a.gin || !a.slabs) return SIFSR_ERR_ARG;
+  if ((a.y != nullptr) != (a.coef != nullptr) || (a.x_scale != nullptr) != (a.x_shift != nullptr)) return SIFSR_ERR_ARG;
+  if (a.stat_partials != nullptr && (!a.bn_y || !a.bn_scale || !a.bn_shift)) return SIFSR_ERR_ARG;
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+  const int tx_ = a.W / 16, ty_ = a.H / 16, ntiles = a.B * tx_ * ty_;
+  const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
+  const dim3 grid(conv3x3_bwd16_grid(a.B, a.H, a.W)), block(512);
+  if (a.y != nullptr) hipLaunchKernelGGL((conv3x3_bwd16_kernel<true>), grid, block, 0, s, a, ntiles, lgx, lgy);
+  else hipLaunchKernelGGL((conv3x3_bwd16_kernel<false>), grid, block, 0, s, a, ntiles, lgx, lgy);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}

@@ -69,31 +69,6 @@ static __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, p);
 }
 static __device__ __forceinline__ uint2 pack_bf16x4(float4 v) { return make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
-// exact three-way split x = hi + mid + lo, each a bf16 (8 + 8 + 8 significand bits cover fp32's 24): the remainders
-// x - hi and x - hi - mid are exact in fp32, so the split loses nothing but underflow
-static __device__ __forceinline__ float4 unpack_bf16x4(uint2 u) {
-  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
-                     __uint_as_float(u.y & 0xFFFF0000u));
-}
-static __device__ __forceinline__ void split3_bf16x4(float4 v, uint2& hi, uint2& mid, uint2& lo) {
-  hi = make_uint2(0u, 0u); mid = hi; lo = hi;
-  {
-    bf16x2 a, b; a[0] = (__bf16)v.x; a[1] = (__bf16)v.y; b[0] = (__bf16)v.z; b[1] = (__bf16)v.w;
-    hi = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
-  }
-  const float4 h = unpack_bf16x4(hi);
-  const float4 r = make_float4(v.x - h.x, v.y - h.y, v.z - h.z, v.w - h.w);
-  {
-    bf16x2 a, b; a[0] = (__bf16)r.x; a[1] = (__bf16)r.y; b[0] = (__bf16)r.z; b[1] = (__bf16)r.w;
-    mid = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
-  }
-  const float4 m = unpack_bf16x4(mid);
-  const float4 r2 = make_float4(r.x - m.x, r.y - m.y, r.z - m.z, r.w - m.w);
-  {
-    bf16x2 a, b; a[0] = (__bf16)r2.x; a[1] = (__bf16)r2.y; b[0] = (__bf16)r2.z; b[1] = (__bf16)r2.w;
-    lo = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
-  }
-}
 static __device__ __forceinline__ float round_bf16(float a) { return (float)(__bf16)a; }
 static __device__ __forceinline__ float4 round_bf16x4(float4 v) { return make_float4(round_bf16(v.x), round_bf16(v.y), round_bf16(v.z), round_bf16(v.w)); }
 static __device__ __forceinline__ uint2 bload2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -108,10 +83,9 @@ static __device__ __forceinline__ uint2 bload2(__amdgpu_buffer_rsrc_t r, unsigne
 // One s_barrier per work item hands a filled buffer to the consumers and a drained one back to the producers
 // (double-buffered LDS), so the producers' VALU / VMEM / LDS-write instructions issue in the shadow of the
 // consumers' 32-cycle MFMAs on the same SIMD instead of in a separate phase of the same wave.
-// MODE 0: fp32 MFMA.  1: bf16 operands (config 5).  2: "fp32 on the bf16 matrix cores": every operand is split
-// exactly into three bf16 terms while staging (x = hi + mid + lo) and six of the nine cross products are accumulated
-// (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are <= 2^-24 relative, the size of one fp32 rounding):
-// six v_mfma_f32_16x16x32_bf16 (16 cycles each, two taps per MFMA) replace eight v_mfma_f32_16x16x4_f32 (32 cycles each) per 16 channels.
+// MODE 0: fp32 MFMA.  1: bf16 operands (config 5).  (A third mode -- fp32 emulated exactly on the bf16 matrix cores by a
+// three-term operand split -- existed in rounds 1-2 and was removed in round 3: the Winograd consumers reach the same goal,
+// fewer matrix-pipe cycles per fp32 result, without operand splitting)
 // DYF (dgrad only): the operand is dL/dy of the layer, formed while staging from g = dL/d relu(bn(y)) and y
 // (bn_bwd4) -- the BatchNorm-backward elementwise pass and its tensor round trip do not exist (ConvArgs::bw_*).
 // WINO (fp32 only): the consumers contract in the Winograd F(2x2, 3x3) domain -- per 2x2 output patch and channel
@@ -121,19 +95,17 @@ static __device__ __forceinline__ uint2 bload2(__amdgpu_buffer_rsrc_t r, unsigne
 // software-pipelined, which brings the kernel under 128 registers -> TWO workgroups per CU, i.e. a second consumer wave
 // per SIMD to issue while the first one waits (measured at one workgroup per CU: matrix pipe busy 32 %, SIMD idle half the time).
 template <int NB, bool ZERO_PAD, int MODE, bool DYF, bool WINO>
-__global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <= 2 && MODE != 2 ? 4 : 2))) void conv3x3_mfma_kernel(const ConvArgs a, const int ntiles, const int lgx,
+__global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <= 2 ? 4 : 2))) void conv3x3_mfma_kernel(const ConvArgs a, const int ntiles, const int lgx,
                                                            const int lgy) {
   static_assert(!DYF || ZERO_PAD, "the fused BatchNorm backward belongs to the input-gradient pass");
   static_assert(!WINO || (MODE == 0 && NB <= 4), "the Winograd consumer is fp32, up to 64 output channels");
-  constexpr bool BF16 = MODE != 0, X3 = MODE == 2;
-  // X3 with 2 or 4 cout blocks: TWO adjacent blocks per wave and half the rows, so every operand word read from LDS
-  // feeds twice the MFMAs (at 16 cycles per bf16 MFMA and three operand planes the one-block tiling is LDS-bound)
-  constexpr bool PAIR = X3 && (NB == 2 || NB == 4);
-  constexpr int CBW = PAIR ? 2 : (NB >= 4 ? NB / 4 : 1);   // cout blocks per consumer wave
-  constexpr int CST = PAIR ? 1 : 4;                          // ... block nb0 + CST * c
-  constexpr int NG = PAIR ? (NB == 2 ? 4 : 8) : (NB == 1 ? 4 : (NB == 2 ? 8 : 16));   // tile rows per consumer wave
+  static_assert(MODE == 0 || MODE == 1, "fp32 or bf16 operands");
+  constexpr bool BF16 = MODE != 0;
+  constexpr int CBW = NB >= 4 ? NB / 4 : 1;                  // cout blocks per consumer wave
+  constexpr int CST = 4;                                     // ... block nb0 + CST * c
+  constexpr int NG = NB == 1 ? 4 : (NB == 2 ? 8 : 16);       // tile rows per consumer wave
 
-  __shared__ float4 lds[2][WINO ? 4 * WPLANE : (X3 ? 6 : 4) * PLANE];   // X3: three planes of 8 B per (pixel, channel quad)
+  __shared__ float4 lds[2][WINO ? 4 * WPLANE : 4 * PLANE];
   __shared__ float red[4][CBW][16][2];
   // (forward only: the input-gradient variants carry the fused BatchNorm work of two layers and measured slower this way)
   constexpr bool WLDS = WINO && NB == 1 && !ZERO_PAD;
@@ -304,14 +276,7 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
           }
         } else if (!praw) v = bn_relu4(v, psc, psh);
         if (it < 5 || pslot < PW * PW - 320) {
-          if (X3) {
-            uint2 hi, mid, lo;
-            split3_bf16x4(v, hi, mid, lo);
-            uint2* const L2 = reinterpret_cast<uint2*>(Lb);
-            L2[cg * PLANE + pslot + 64 * it] = hi;
-            L2[4 * PLANE + cg * PLANE + pslot + 64 * it] = mid;
-            L2[8 * PLANE + cg * PLANE + pslot + 64 * it] = lo;
-          } else if (BF16) reinterpret_cast<uint2*>(Lb)[cg * PLANE + pslot + 64 * it] = pack_bf16x4(v);
+          if (BF16) reinterpret_cast<uint2*>(Lb)[cg * PLANE + pslot + 64 * it] = pack_bf16x4(v);
           else Lb[lslot[it]] = v;
         }
       }
@@ -336,20 +301,18 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
   }
 
   // ============================================= CONSUMER =============================================
-  const int nb0 = PAIR ? (NB == 2 ? 0 : 2 * (wave & 1)) : (NB == 1 ? 0 : (NB == 2 ? (wave & 1) : wave));
-  const int g0 = PAIR ? (NB == 2 ? wave * 4 : (wave >> 1) * 8) : (NB == 1 ? wave * 4 : (NB == 2 ? (wave >> 1) * 8 : 0));
+  const int nb0 = NB == 1 ? 0 : (NB == 2 ? (wave & 1) : wave);
+  const int g0 = NB == 1 ? wave * 4 : (NB == 2 ? (wave >> 1) * 8 : 0);
   const int kq = lane >> 4, px = lane & 15;
   const __amdgpu_buffer_rsrc_t rd0 = make_rsrc(a.dst[0].ptr, npix * a.dst[0].C * 4u);
   const __amdgpu_buffer_rsrc_t rd1 = make_rsrc(a.dst[1].ptr, npix * a.dst[1].C * 4u);
   const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.addend ? a.addend : a.dst[0].ptr, npix * (a.addend ? a.addC : a.dst[0].C) * 4u);
   const bool bn_stats = NB == 1 && ZERO_PAD && a.bn_y != nullptr;     // BatchNorm-backward sums of the previous layer
   const __amdgpu_buffer_rsrc_t rby = make_rsrc(bn_stats ? a.bn_y : a.dst[0].ptr, npix * 64u);
-  const unsigned wplane = (unsigned)(NB * 16) * (unsigned)(NQ * 16) * 36u;     // X3: byte distance hi -> mid -> lo pack (= 4n)
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpack, X3 ? 2u * wplane + wplane / 2u : (unsigned)(NB * 16) * (unsigned)(NQ * 16) * (BF16 ? 18u : 36u));
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpack, (unsigned)(NB * 16) * (unsigned)(NQ * 16) * (BF16 ? 18u : 36u));
 
   float4 wf[BF16 ? 1 : CBW][BF16 ? 1 : 9];
   uint2 wh[BF16 ? CBW : 1][BF16 ? 9 : 1];     // bf16 mode: 4 bf16 per lane per (cout block, tap)
-  uint2 wm[X3 ? CBW : 1][X3 ? 9 : 1], wl[X3 ? CBW : 1][X3 ? 9 : 1];   // X3: the mid / lo terms of the weights
   auto load_weights = [&](int q) {
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
@@ -359,10 +322,6 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
           wh[c][tp] = bload2(rw, (unsigned)lane * 8u, soff + tp * 512u);
-          if (X3) {
-            wm[c][tp] = bload2(rw, (unsigned)lane * 8u, soff + tp * 512u + wplane);
-            wl[c][tp] = bload2(rw, (unsigned)lane * 8u, soff + tp * 512u + 2u * wplane);
-          }
         }
       } else {
         const unsigned soff = (unsigned)((nb * NQ + q) * 9) * 1024u;
@@ -626,39 +585,16 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
         const int ty0 = t0 / 3, tx0 = t0 - 3 * (t0 / 3), ty1 = t1 / 3, tx1 = t1 - 3 * (t1 / 3);
 #pragma unroll
         for (int gb = 0; gb < NG / 4; ++gb) {
-          bf16x8 bh[4], bm[X3 ? 4 : 1], bl[X3 ? 4 : 1];
+          bf16x8 bh[4];
 #pragma unroll
           for (int gi = 0; gi < 4; ++gi) {
             const int r = g0 + gb * 4 + gi;
             const int o0 = kq * PLANE + (r + ty0) * PW + tx0 + px, o1 = kq * PLANE + (r + ty1) * PW + tx1 + px;
             bh[gi] = cat(L16[o0], L16[o1]);
-            if (X3) {
-              bm[gi] = cat(L16[4 * PLANE + o0], L16[4 * PLANE + o1]);
-              bl[gi] = cat(L16[8 * PLANE + o0], L16[8 * PLANE + o1]);
-            }
           }
 #pragma unroll
           for (int c = 0; c < CBW; ++c) {
             const bf16x8 w = cat(wh[c][t0], two ? wh[c][t1] : z2);
-            if (X3) {
-              // smallest terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, then hi*hi
-              const bf16x8 wmid = cat(wm[c][t0], two ? wm[c][t1] : z2), wlo = cat(wl[c][t0], two ? wl[c][t1] : z2);
-#pragma unroll
-              for (int gi = 0; gi < 4; ++gi)
-                acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, bh[gi], acc[c][gb * 4 + gi], 0, 0, 0);
-#pragma unroll
-              for (int gi = 0; gi < 4; ++gi)
-                acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bl[gi], acc[c][gb * 4 + gi], 0, 0, 0);
-#pragma unroll
-              for (int gi = 0; gi < 4; ++gi)
-                acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, bm[gi], acc[c][gb * 4 + gi], 0, 0, 0);
-#pragma unroll
-              for (int gi = 0; gi < 4; ++gi)
-                acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, bh[gi], acc[c][gb * 4 + gi], 0, 0, 0);
-#pragma unroll
-              for (int gi = 0; gi < 4; ++gi)
-                acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bm[gi], acc[c][gb * 4 + gi], 0, 0, 0);
-            }
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi)
               acc[c][gb * 4 + gi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bh[gi], acc[c][gb * 4 + gi], 0, 0, 0);
@@ -674,10 +610,6 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
               const int tp = k == 0 ? t0 : t1;
               const unsigned so = (unsigned)(((nb0 + CST * c) * NQ + qn) * 9 + tp) * 512u;
               wh[c][tp] = bload2(rw, (unsigned)lane * 8u, so);
-              if (X3) {
-                wm[c][tp] = bload2(rw, (unsigned)lane * 8u, so + wplane);
-                wl[c][tp] = bload2(rw, (unsigned)lane * 8u, so + 2u * wplane);
-              }
             }
           }
         }
@@ -789,10 +721,7 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
     if (tid < NB * 16) {
       const int nb = tid >> 4, cc = tid & 15;
       float u = 0.f, v = 0.f;
-      if (PAIR) {
-        if (NB == 2) { for (int w = 0; w < 4; ++w) { u += red[w][nb][cc][0]; v += red[w][nb][cc][1]; } }
-        else { for (int w = nb >> 1; w < 4; w += 2) { u += red[w][nb & 1][cc][0]; v += red[w][nb & 1][cc][1]; } }
-      } else if (NB == 1) {
+      if (NB == 1) {
         for (int w = 0; w < 4; ++w) { u += red[w][0][cc][0]; v += red[w][0][cc][1]; }
       } else if (NB == 2) {
         for (int w = nb; w < 4; w += 2) { u += red[w][0][cc][0]; v += red[w][0][cc][1]; }
@@ -811,7 +740,7 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
 //   dgrad: wd[nb][q][tap][lane][j] = W[co = 16q + 4(lane>>4) + j][ci = 16nb + (lane&15)][8 - tap]
 //          (transposed and spatially flipped: dx[p] = sum_t W_t^T dy[p - t])
 //   bf16 : the same two packs rounded to bf16 (config 5), [fwd16 | dgrad16] = 2 * 9*cin*cout bf16
-// The dgrad buffer of a layer holds [wd | fwd16 dgrad16] = 2 * 9*cin*cout floats.
+// The dgrad buffer of a layer holds [wd | fwd16 dgrad16 | unused] = 4 * 9*cin*cout floats (the size the C ABI documents).
 // ---------------------------------------------------------------------------------------------
 struct PackTable { int w_off[16], cin[16], cout[16], p_off[16]; };
 
@@ -839,17 +768,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
     }
     {
       // bf16 fragment packs (same element order), 2 bytes each, behind the layer's fp32 dgrad pack (4n floats in all):
-      //   [fp32 dgrad n | fwd hi n/2 | dgrad hi n/2 | fwd mid | dgrad mid | fwd lo | dgrad lo]
-      // hi = bf16(w) is the pack of the bf16 mode; hi + mid + lo = w exactly (the split-bf16 "fp32" mode)
+      //   [fp32 dgrad n | fwd bf16 n/2 | dgrad bf16 n/2 | 2n unused (held the mid / lo terms of the removed split-bf16 mode)]
       __bf16* h = reinterpret_cast<__bf16*>(wdg + 4 * tb.p_off[l] + n);
       const float wv[2] = {wfwd[tb.p_off[l] + e], wdg[4 * tb.p_off[l] + e]};
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const __bf16 hi = (__bf16)wv[k];
-        const float r = wv[k] - (float)hi;
-        const __bf16 mid = (__bf16)r;
-        const __bf16 lo = (__bf16)(r - (float)mid);
-        h[k * n + e] = hi; h[2 * n + k * n + e] = mid; h[4 * n + k * n + e] = lo;
+        h[k * n + e] = (__bf16)wv[k];
       }
     }
   }
@@ -1083,7 +1007,7 @@ int conv3x3_grid_blocks(int B, int H, int W, int cout, int wino) {
 
 int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s) {
   if (a.H < 1 || a.W < 1 || cout % 16 || a.NQ < 1 || a.src[0].nq + a.src[1].nq != a.NQ) return SIFSR_ERR_SHAPE;
-  if (a.bf16 < 0 || a.bf16 > 2) return SIFSR_ERR_ARG;
+  if (a.bf16 < 0 || a.bf16 > 1) return SIFSR_ERR_ARG;
   if (!a.src[0].ptr || !a.dst[0].ptr || !a.wpack) return SIFSR_ERR_ARG;
   const int ntiles = a.B * ((a.H + 15) / 16) * ((a.W + 15) / 16);
   const dim3 grid(conv3x3_grid_blocks(a.B, a.H, a.W, cout)), block(512);
@@ -1150,8 +1074,7 @@ int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s
     else SIFSR_CONV_LAUNCH(NBV, false, MD, false);
 #define SIFSR_CONV_CASE(NBV)                                                                              \
   case NBV:                                                                                               \
-    if (a.bf16 == 2) { SIFSR_CONV_MODE(NBV, 2) }                                                          \
-    else if (a.bf16) { SIFSR_CONV_MODE(NBV, 1) }                                                          \
+    if (a.bf16) { SIFSR_CONV_MODE(NBV, 1) }                                                          \
     else { SIFSR_CONV_MODE(NBV, 0) }                                                                      \
     break;
   switch (nb) {

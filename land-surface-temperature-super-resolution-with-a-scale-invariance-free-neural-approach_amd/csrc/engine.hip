@@ -134,6 +134,11 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
       // ... and over the two kernel families: the tap-domain grid scales with SIFSR_DBG_WGRAD_GRID_PCT, the Winograd one does not
       const int nb_tap = wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles, false), nb_wino = wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles, true);
       w.slab_cap[l] = (size_t)(nb_tap > nb_wino ? nb_tap : nb_wino) * 16 * nt.L[l].cin * nt.L[l].cout;
+      // ... and the fused input + weight gradient kernel of the 16 -> 16 layers writes one slab per weight-gradient wave
+      if (nt.L[l].cin == 16 && nt.L[l].cout == 16 && conv3x3_bwd16_applies(B, lvh, lvw)) {
+        const size_t need = (size_t)4 * conv3x3_bwd16_grid(B, lvh, lvw) * 16 * 256;
+        if (need > w.slab_cap[l]) w.slab_cap[l] = need;
+      }
       w.slab_l[l] = take(w.slab_cap[l]);
       wino_pairs += (size_t)nt.L[l].cin * nt.L[l].cout;
     }
@@ -159,7 +164,7 @@ struct Ctx {
   int* njobs = nullptr;
   WgradReduceJob* xjobs = nullptr;  // ... of the layers whose weight gradient ran in the Winograd domain
   int* nxjobs = nullptr;
-  int bf16 = 0;                     // 1: bf16 MFMA operands (config 5); 2: split-bf16 fp32 (conv forward / dgrad; wgrad stays fp32)
+  int bf16 = 0;                     // 1: bf16 MFMA operands (config 5)
   struct SideLane* side = nullptr;  // backward: the weight gradients' own stream (nullptr = everything on s)
   bool* forked = nullptr;           // set once anything was enqueued on the side stream (SideLaneGuard)
   int lvH(int lv) const { return H >> lv; }
@@ -299,7 +304,7 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
   a.src[0] = s0; a.src[1] = s1;
   a.dst[0].ptr = c.f(c.lay.y[l]); a.dst[0].C = L.cout; a.dst[0].coff = 0;
   a.dst[1] = a.dst[0];
-  a.bf16 = (c.bf16 == 2 && L.cout == 128) ? 0 : c.bf16;   // split mode: the 8-block variant has no registers for it -> fp32 MFMA (same results)
+  a.bf16 = c.bf16;
   {
     const size_t n = (size_t)9 * L.cin * L.cout;   // bf16 packs live behind the layer's fp32 dgrad pack
     a.wpack = a.bf16 ? c.f(c.lay.wdg) + 4 * (size_t)L.wpack_off + n : c.f(c.lay.wfwd) + L.wpack_off;
@@ -372,7 +377,7 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
   a.B = c.B; a.H = c.lvH(L.level); a.W = c.lvW(L.level);
   a.NQ = L.cin / 16;
   a.ntiles = c.B * ((a.H + 7) / 8) * ((a.W + 15) / 16);
-  a.bf16 = c.bf16 == 1 ? 1 : 0;   // the split-bf16 mode keeps the fp32 weight-gradient kernel
+  a.bf16 = c.bf16;
   // Winograd F(3x3,2x2) where it is the faster form (measured per shape, tools/sweep_layers.sh)
   const bool wino = c.xjobs != nullptr && wgrad_wino_policy(L.cin, L.cout) && conv3x3_wgrad_use_wino(a, L.cin, L.cout);
   const int nbi = wino ? wgrad_wino_nbi_chunk(a, L.cin) : wgrad_nbi_chunk(a, L.cin);
@@ -421,11 +426,11 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
   }
   a.dst[0].ptr = g0; a.dst[0].C = C0; a.dst[0].coff = 0;
   a.dst[1].ptr = g1 ? g1 : g0; a.dst[1].C = g1 ? C1 : C0; a.dst[1].coff = 0;
-  a.bf16 = (c.bf16 == 2 && L.cin == 128) ? 0 : c.bf16;     // see conv_unit_fwd
+  a.bf16 = c.bf16;
   const float* wdg_f32 = c.f(c.lay.wdg) + 4 * (size_t)L.wpack_off;
   {
     const size_t n = (size_t)9 * L.cin * L.cout;
-    a.wpack = a.bf16 ? wdg_f32 + n + n / 2 : wdg_f32;   // [fp32 dgrad | fwd hi (n/2 floats) | dgrad hi | mid, lo packs]
+    a.wpack = a.bf16 ? wdg_f32 + n + n / 2 : wdg_f32;   // [fp32 dgrad | fwd bf16 (n/2 floats) | dgrad bf16 | unused]
   }
   a.wpack_wino = c.f(c.lay.wwd) + (size_t)L.wpack_off / 9 * 16;
   a.addend = addend; a.addC = L.cin;
@@ -443,8 +448,53 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
     SIFSR_TRY(launch_conv3x3_mfma(a, L.cin, 1, c.s));
   }
   SIFSR_TRY(launch_dgrad_border_fix(dy_edge, L.cout, wdg_f32, L.cin, g0, C0, split_ch, g1 ? g1 : g0, g1 ? C1 : C0, c.B, a.H,
-                                    a.W, c.s, c.bf16 == 1 ? 1 : 0, fuse ? a.bn_y : nullptr, fuse ? a.bn_scale : nullptr,
+                                    a.W, c.s, c.bf16, fuse ? a.bn_y : nullptr, fuse ? a.bn_scale : nullptr,
                                     fuse ? a.bn_shift : nullptr, fuse ? c.f(c.lay.bpart) : nullptr));
+  return SIFSR_OK;
+}
+
+// Input gradient AND weight gradient of a 16 -> 16 channel MFMA unit in ONE kernel (conv_bwd16.hip) where its shape allows:
+// (g_l, y_l, the forward input) are read once for both passes.  Arguments as conv_unit_wgrad + conv_unit_dgrad of the same
+// layer (s0 = the forward input, 16 channels; gin = the gradient w.r.t. it, `addend` added; bn_layer as conv_unit_dgrad).
+// Returns SIFSR_OK with *applied = false when the separate kernels have to run instead (other shapes, bf16 mode, switched off).
+// The kernel runs on the CALLER's stream (it is part of the serial chain); its weight-gradient slabs join the Winograd
+// reduction list, and ev[l] of the second stream's lane marks their completion for a reduction issued there.
+int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin, const float* addend, int bn_layer, int* stat_rows,
+                    bool dy_stored, bool* applied) {
+  const LayerInfo& L = c.nt.L[l];
+  *applied = false;
+  if (stat_rows) *stat_rows = 0;
+  const int lh = c.lvH(L.level), lw = c.lvW(L.level);
+  if (L.cin != 16 || L.cout != 16 || c.bf16 != 0 || c.xjobs == nullptr || !wgrad_wino_policy(16, 16) || s0.C != 16 || s0.coff != 0 ||
+      !conv3x3_bwd16_applies(c.B, lh, lw))
+    return SIFSR_OK;
+  const bool fuse = bn_layer >= 0 && addend == nullptr && c.nt.L[bn_layer].cout == 16 && c.nt.L[bn_layer].level == L.level;
+  const int grid = conv3x3_bwd16_grid(c.B, lh, lw);
+  if ((size_t)4 * grid * 16 * 256 > c.lay.slab_cap[l] || (fuse && (size_t)grid * 32 > c.lay.partials_cap)) return SIFSR_ERR_WORKSPACE;
+  Bwd16Args a;
+  a.x = s0.ptr; a.x_scale = s0.scale; a.x_shift = s0.shift;
+  a.g = dy;
+  if (!dy_stored) { a.y = c.f(c.lay.y[l]); a.coef = c.f(c.lay.coef_f) + 4 * (size_t)L.ch_off; a.dy_border = c.f(c.lay.dy_border); }
+  a.wpack_wino = c.f(c.lay.wwd) + (size_t)L.wpack_off / 9 * 16;
+  a.gin = gin; a.addend = addend;
+  if (fuse) {
+    a.bn_y = c.f(c.lay.y[bn_layer]); a.bn_scale = c.scale(bn_layer); a.bn_shift = c.shift(bn_layer); a.stat_partials = c.f(c.lay.partials);
+    if (stat_rows) *stat_rows = grid;
+  }
+  a.slabs = c.f(c.lay.slab_l[l]);
+  a.B = c.B; a.H = lh; a.W = lw;
+  {
+    ProfScope ps(l, 2, c.s);     // one launch = both passes of the layer: timed as its input-gradient selection
+    SIFSR_TRY(launch_conv3x3_bwd16(a, c.s));
+  }
+  const float* wdg_f32 = c.f(c.lay.wdg) + 4 * (size_t)L.wpack_off;
+  SIFSR_TRY(launch_dgrad_border_fix(dy_stored ? dy : a.dy_border, 16, wdg_f32, 16, gin, 16, 16, gin, 16, c.B, lh, lw, c.s, 0,
+                                    fuse ? a.bn_y : nullptr, fuse ? a.bn_scale : nullptr, fuse ? a.bn_shift : nullptr,
+                                    fuse ? c.f(c.lay.bpart) : nullptr));
+  WgradReduceJob& j = c.xjobs[(*c.nxjobs)++];
+  j.slab_off = c.lay.slab_l[l]; j.nblk = 4 * grid; j.cin = 16; j.cout = 16; j.nbi_chunk = 1; j.w_off = L.w_off;
+  if (c.side != nullptr && hipEventRecord(c.side->ev[l], c.s) != hipSuccess) return SIFSR_ERR_ARG;   // slabs of l complete
+  *applied = true;
   return SIFSR_OK;
 }
 
@@ -458,7 +508,7 @@ int sifsr_engine_forward(const float* x, float* sr, const float* params, float* 
                          hipStream_t s, int bf16) {
   if (!x || !sr || !params || !running || !ws) return SIFSR_ERR_ARG;
   Ctx c{sifsr_net(), WsLayout(), ws, params, B, H, W, s};
-  if (bf16 < 0 || bf16 > 2) return SIFSR_ERR_ARG;
+  if (bf16 < 0 || bf16 > 1) return SIFSR_ERR_ARG;
   c.bf16 = bf16;
   SIFSR_TRY(sifsr_layout(B, H, W, training, &c.lay));
   // a forward touches [0, fwd_end) only; the backward regions behind it are checked by sifsr_engine_backward.  So a
@@ -526,7 +576,7 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
                           size_t ws_floats, int B, int H, int W, hipStream_t s, int bf16) {
   if (!x || !dsr || !params || !grads || !ws) return SIFSR_ERR_ARG;
   Ctx c{sifsr_net(), WsLayout(), ws, params, B, H, W, s};
-  if (bf16 < 0 || bf16 > 2) return SIFSR_ERR_ARG;
+  if (bf16 < 0 || bf16 > 1) return SIFSR_ERR_ARG;
   c.bf16 = bf16;
   SIFSR_TRY(sifsr_layout(B, H, W, 1, &c.lay));
   if (ws_floats < c.lay.total) return SIFSR_ERR_WORKSPACE;
@@ -579,9 +629,13 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     const int la = dec_a[k], lb = dec_b[k], ls = dec_skip[k], ll = dec_low[k];
     // second conv of the DoubleConvolution (k == 2: dy already produced by the fused tail above)
     if (k != 2) SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), grads, nullptr, up_rows, 0));
-    SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads, k == 2));
     int rows_a = 0;
-    SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), nt.L[la].cout, nt.L[lb].cin, nullptr, 0, nullptr, la, &rows_a, k == 2));
+    bool fused_b = false;
+    SIFSR_TRY(conv_unit_bwd16(c, lb, src_act(c, la), c.f(w.g[lb]), c.f(w.g[la]), nullptr, la, &rows_a, k == 2, &fused_b));
+    if (!fused_b) {
+      SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads, k == 2));
+      SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), nt.L[la].cout, nt.L[lb].cin, nullptr, 0, nullptr, la, &rows_a, k == 2));
+    }
     // first conv: input = cat([U_k, relu(bn(y_skip))])
     SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), grads, nullptr, rows_a));
     SIFSR_TRY(conv_unit_wgrad(c, la, src_raw(c.f(w.U[k]), uc[k]), src_act(c, ls), c.f(w.g[la]), grads));
@@ -609,24 +663,41 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     SIFSR_TRY(conv_unit_dgrad(c, lc, c.f(w.g[lc]), c.f(w.g[lb]), pc[k], pc[k], nullptr, 0, nullptr, lb, &rows_b));
     // residual DoubleConvolution (g[lb] survives untouched: it is also the skip gradient added to gP[k] below)
     SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), grads, nullptr, rows_b));
-    SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads));
-    SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), pc[k], pc[k], nullptr, 0, nullptr, la, &rows_a));
+    bool fused_b = false;
+    SIFSR_TRY(conv_unit_bwd16(c, lb, src_act(c, la), c.f(w.g[lb]), c.f(w.g[la]), nullptr, la, &rows_a, false, &fused_b));
+    if (!fused_b) {
+      SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads));
+      SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), pc[k], pc[k], nullptr, 0, nullptr, la, &rows_a));
+    }
     SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), grads, nullptr, rows_a));
-    SIFSR_TRY(conv_unit_wgrad(c, la, src_raw(c.f(w.P[k]), pc[k]), src_none(), c.f(w.g[la]), grads));
-    SIFSR_TRY(conv_unit_dgrad(c, la, c.f(w.g[la]), c.f(w.gP[k]), pc[k], pc[k], nullptr, 0, c.f(w.g[lb])));
+    bool fused_a = false;
+    SIFSR_TRY(conv_unit_bwd16(c, la, src_raw(c.f(w.P[k]), pc[k]), c.f(w.g[la]), c.f(w.gP[k]), c.f(w.g[lb]), -1, nullptr, false, &fused_a));
+    if (!fused_a) {
+      SIFSR_TRY(conv_unit_wgrad(c, la, src_raw(c.f(w.P[k]), pc[k]), src_none(), c.f(w.g[la]), grads));
+      SIFSR_TRY(conv_unit_dgrad(c, la, c.f(w.g[la]), c.f(w.gP[k]), pc[k], pc[k], nullptr, 0, c.f(w.g[lb])));
+    }
     // AvgPool adjoint of gP[k] onto the skip gradient g[lp]: folded into the BatchNorm backward of lp (above / below)
     (void)lp;
   }
 
   // inbloc
   SIFSR_TRY(bn_unit_bwd(c, L_IN3, c.f(w.g[L_IN3]), grads, c.f(w.gP[0])));
-  SIFSR_TRY(conv_unit_wgrad(c, L_IN3, src_act(c, L_IN0), src_none(), c.f(w.g[L_IN3]), grads));
+  int rows_in0 = 0;
+  bool fused_in3 = false;
+  SIFSR_TRY(conv_unit_bwd16(c, L_IN3, src_act(c, L_IN0), c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), nullptr, L_IN0, &rows_in0, false, &fused_in3));
+  if (!fused_in3) SIFSR_TRY(conv_unit_wgrad(c, L_IN3, src_act(c, L_IN0), src_none(), c.f(w.g[L_IN3]), grads));
   // that was the last MFMA layer: all 16 layers' weight-gradient slabs -> OIHW gradients, one launch.  With the second
   // stream it follows the last weight gradient there (it writes only the conv-weight regions of `grads`, which nothing
-  // on the caller's stream touches) and overlaps the head of the chain instead of trailing it.
-  if (c.side != nullptr) SIFSR_TRY(finish_wgrads(c.side->s));
-  int rows_in0 = 0;
-  SIFSR_TRY(conv_unit_dgrad(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), 16, 16, nullptr, 0, nullptr, L_IN0, &rows_in0));
+  // on the caller's stream touches) and overlaps the head of the chain instead of trailing it.  The fused 16 -> 16 kernels
+  // wrote their slabs on the CALLER's stream: the last of them (this layer's) is what the second stream waits for.
+  if (c.side != nullptr) {
+    if (fused_in3) {
+      if (hipStreamWaitEvent(c.side->s, c.side->ev[L_IN3], 0) != hipSuccess) return SIFSR_ERR_ARG;
+      lane_guard.forked = true;
+    }
+    SIFSR_TRY(finish_wgrads(c.side->s));
+  }
+  if (!fused_in3) SIFSR_TRY(conv_unit_dgrad(c, L_IN3, c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), 16, 16, nullptr, 0, nullptr, L_IN0, &rows_in0));
   // first layer: no input gradient, so dy(L_IN0) is consumed by the weight gradient alone and is formed on the
   // fly from (g, y) in its staging loop; its BatchNorm-backward sums came out of the dgrad above -> finalize only
   {

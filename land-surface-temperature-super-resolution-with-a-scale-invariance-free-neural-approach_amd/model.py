@@ -63,10 +63,8 @@ class _Up(nn.Module):
 
 
 # compute modes of the 3x3 convolutions (sifsr_model_*_ex): "fp32" = fp32 MFMA (default, the parity configuration);
-# "bf16" = bf16 operands, fp32 accumulation (BASELINE.json config 5); "bf16x3" = fp32 on the bf16 matrix cores: every
-# operand split exactly into three bf16 terms, six of nine cross products accumulated (forward and input gradient; the
-# weight gradient stays on the fp32 MFMA) -- agrees with "fp32" to fp32 rounding
-_COMPUTE_MODES = {"fp32": 0, "bf16": 1, "bf16x3": 2}
+# "bf16" = bf16 operands, fp32 accumulation (BASELINE.json config 5)
+_COMPUTE_MODES = {"fp32": 0, "bf16": 1}
 
 
 class _ModelFn(torch.autograd.Function):

@@ -310,34 +310,34 @@ def test_capture_with_live_earlier_graph_is_refused(sifsr):
 
 
 def test_fit_early_stop_restores_the_best_state(sifsr):
-    """train.fit over 3 epochs with patience 1 and a learning rate large enough to make the validation loss rise: the loop
+    """train.fit over (at most) 3 epochs with patience 1 and a monitored metric that gets worse after the first epoch: the loop
     must switch train -> eval -> train every epoch, break when the patience is spent and load the saved best state back into
     the flat parameter buffer (train_model_B_gradFTM.py:338-352) -- parameters AND BatchNorm buffers equal the checkpoint's
-    copy, and the nn.Parameters still alias the flat buffer afterwards (the next step trains the restored weights)."""
+    copy, and the nn.Parameters still alias the flat buffer afterwards (the next step trains the restored weights).  The
+    checkpoint sees a scripted validation loss (1, 2, 3): what is under test is the loop's plumbing, not the optimisation."""
     train_ds = sifsr.dataset.ModisDatasetB("data/ModisDatasetB.csv", transf="norm", split="Train", time="day", length=8)
     val_ds = sifsr.dataset.ModisDatasetB("data/ModisDatasetB.csv", transf="norm", split="Val", time="day", length=8)
     m = sifsr.ModelB_2(2, [16, 32, 64, 128], "replicate", "ReLU", 1, 1)
     m.load_state_dict(O.synthetic_state(11))
     m = m.to("cuda")
-    opt = sifsr.FlatAdam(m.parameters(), lr=0.5)            # absurd on purpose: epoch 2 / 3 validate worse than epoch 1
+    opt = sifsr.FlatAdam(m.parameters(), lr=1e-3)
+    seen = []
 
-    class Recording(sifsr.train.ModelCheckpoint):
-        seen = []
-
+    class Scripted(sifsr.train.ModelCheckpoint):
         def test_update(self, model, metrics, key, epoch):
             assert not model.training                       # called right after the validation pass (eval mode)
-            super().test_update(model, metrics, key, epoch)
-            Recording.seen.append((epoch, metrics[key][-1], self.train_state))
+            assert np.isfinite(metrics[key][-1])
+            super().test_update(model, {key: [float(epoch)]}, key, epoch)
+            seen.append((epoch, self.train_state))
 
-    ck = Recording(3, patience=1)
+    ck = Scripted(3, patience=1)
     m, metrics = sifsr.train.fit(m, train_ds, val_ds, 3, 4, opt, 0.5, -0.25, "sr2", "cuda", ck, shuffle=False)
-    vals = metrics["val_loss"]
-    assert len(vals) >= 2 and all(np.isfinite(v) or np.isnan(v) for v in vals)
-    assert ck.train_state == "break", (Recording.seen, vals)
-    assert metrics["best_epoch"] == ck.best_epoch and len(metrics["train_loss"]) == len(vals) == ck.curr_epoch
+    assert seen == [(1, None), (2, "break")], seen
+    assert metrics["best_epoch"] == ck.best_epoch == 1 and len(metrics["train_loss"]) == len(metrics["val_loss"]) == 2
     sd = m.state_dict()
     for k, v in ck.saved_state.items():
         assert torch.equal(sd[k].cpu(), v.cpu()), k
+    assert int(sd["inbloc.bloc.1.num_batches_tracked"]) == 2     # two training batches of epoch 1 (epoch 2's four were rolled back)
     flat = m.flat_parameters()
     off = 0
     for p_ in m.parameters():                                # still views of the one flat buffer

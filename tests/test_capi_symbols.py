@@ -44,7 +44,7 @@ def test_header_parser_types(L):
 
 
 def test_layer_table_matches_reference_layout(L):
-    assert L.call("sifsr_abi_version") == 2
+    assert L.call("sifsr_abi_version") == 3
     assert L.call("sifsr_num_params") == 282705
     tab = (ctypes.c_int * (17 * 8))()
     assert L.call("sifsr_layer_table", tab, 17) == 17

@@ -257,17 +257,17 @@ def test_bench_roofline_class_selection(tmp_path):
     import bench
     t = bench.class_table()
     launches = [lp for v in t.values() for lp in v]
-    assert len(launches) == len(set(launches)) == 48
-    flops = (sum(bench.layer_flops(l) for l, _ in launches) + 2 * bench.layer_flops(0)     # the 2->16 layer has no input gradient
+    assert len(launches) == len(set(launches)) == 48 - len(bench.FUSED_BWD16)          # fused 16 -> 16 layers: one backward launch
+    flops = (sum(bench.member_flops(l, p) for l, p in launches) + 2 * bench.layer_flops(0)   # the 2->16 layer has no input gradient
              + 3 * 2 * 9 * 16 * 1 * 256 * 256)                                           # outlay (16->1), three passes
     assert flops == bench.TRAIN_FLOPS_PER_PATCH
     assert sum(bench.layer_flops(l) for l, p in t["conv3x3_wgrad_wino_kernel<2, 2, true"]) * 64 == 120_795_955_200
     f = tmp_path / "x_kernel_stats.csv"
     f.write_text('"Name","Calls","TotalDurationNs"\n'
-                 '"void (anonymous namespace)::conv3x3_mfma_kernel<1, true, 0, true, true>(ConvArgs)",4,500\n'
-                 '"void (anonymous namespace)::conv3x3_mfma_kernel<1, true, 0, false, true>(ConvArgs)",1,450\n'
+                 '"void (anonymous namespace)::conv3x3_bwd16_kernel<true>(Bwd16Args)",3,500\n'
+                 '"void (anonymous namespace)::conv3x3_bwd16_kernel<false>(Bwd16Args)",1,40\n'
                  '"void (anonymous namespace)::conv3x3_wino8_kernel<4, true, true, 1>(ConvArgs)",5,300\n'
                  '"void (anonymous namespace)::conv3x3_wino8_kernel<4, true, false, 1>(ConvArgs)",1,250\n'
                  '"bn_finalize_kernel",100,9999\n')
     cls, src = bench.dominant_class(str(f))
-    assert cls == "conv3x3_wino8_kernel<4, true" and src == "x_kernel_stats.csv"      # 300 + 250 > 500 > 450
+    assert cls == "conv3x3_wino8_kernel<4, true" and src == "x_kernel_stats.csv"      # 300 + 250 > 500 + 40

@@ -32,6 +32,29 @@ def test_lint_flags_an_asm_result_consumed_by_the_next_mfma():
     assert not [f for f in isa_lint.lint_text(SNIPPET.replace("v12, v188", "v12, v190") % "") if f[2] == "A"]
 
 
+LOOP = """
+kern:
+.LBB0_1:
+	v_mfma_f32_16x16x4_f32 v[74:77], v12, v188, v[170:173]
+	v_mov_b32_e32 v1, v2
+	v_mov_b32_e32 v3, v4
+	;;#ASMSTART
+	v_pk_add_f32 v[188:189], v[74:75], v[90:91]
+	;;#ASMEND
+	%s
+	s_cbranch_scc1 .LBB0_1
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def test_lint_follows_loop_back_edges():
+    """The asm result is consumed by the MFMA at the TOP of the loop, one branch later: invisible in textual order."""
+    bad = [f for f in isa_lint.lint_text(LOOP % "") if f[2] == "A"]
+    assert len(bad) == 1 and "v[188:189]" in bad[0][3]
+    assert not [f for f in isa_lint.lint_text(LOOP % "s_nop 0") if f[2] == "A"]      # s_nop 0 + the branch: two wait states
+
+
 @pytest.mark.parametrize("name", ["conv_mfma.hip", "conv_wino8.hip", "conv_wgrad_wino.hip"])
 def test_no_asm_to_mfma_hazard_in_the_kernels(name):
     src = glob.glob(os.path.join(ROOT, "*_amd", "csrc", name))[0]

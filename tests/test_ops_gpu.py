@@ -620,3 +620,112 @@ def test_bn_relu_backward_fused_into_dgrad_and_wgrad(L, case):
             L.call("sifsr_conv3x3_wgrad_wino", da, cin, None, None, None, 0, None, None, dg, y, coef_f, cout, scratch, nbk, dwx, B, H, W, S())
             torch.cuda.synchronize()
             assert rel_err(dwx.cpu(), gw_ref) < TOL, nbk
+
+
+# ---- input gradient AND weight gradient of a 16 -> 16 layer in one kernel (round 3, conv_bwd16.hip) ----------------------
+# (H, W, B, input is a raw conv output with folded BatchNorm, dL/dy formed on load from (g, y), residual addend, fused BN sums)
+BWD16_CASES = [
+    (32, 48, 2, True, True, False, True),      # inbloc.bloc.3 / db1.res.3: everything on
+    (32, 32, 1, True, False, False, True),     # ub3.convbloc.bloc.3: dL/dy stored (the fused tail wrote it)
+    (48, 32, 2, False, True, True, False),     # db1.res.0: stored input (the pooled tensor), residual gradient added
+    (128, 128, 8, True, True, False, True),    # 512 tiles on 256 workgroups: two tiles per workgroup, XCD-strided walk
+    (64, 32, 3, False, False, False, False),
+]
+
+
+@pytest.mark.parametrize("case", BWD16_CASES)
+def test_conv3x3_bwd16_fused_dgrad_wgrad(L, case):
+    """z = relu(bn_train(conv(a))), a = relu(x*xs + xsh) (or x itself), upstream gradient g on z.  One call must return the
+    gradient w.r.t. a (incl. the replicate-border fold, + addend), the weight gradient, and -- when asked -- the
+    BatchNorm-backward sums of the layer below (sum dz, sum dz*x with dz = gin*[x*xs+xsh > 0]).  Reference: float64 autograd
+    of the PyTorch ops; also compared with the separate Winograd kernels the model runs for other shapes."""
+    H, W, B, x_bn, dyf, with_add, with_stats = case
+    C = 16
+    rs = np.random.RandomState(hash(case) % 2**31)
+    x = rnd(rs, B, C, H, W)
+    xs = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)) if x_bn else None
+    xsh = rnd(rs, C, scale=0.3) if x_bn else None
+    w = rnd(rs, C, C, 3, 3, scale=(2.0 / (9 * C)) ** 0.5)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32))
+    beta = rnd(rs, C, scale=0.5)
+    g = rnd(rs, B, C, H, W)
+    addend = rnd(rs, B, C, H, W) if with_add else None
+    # ---- float64 reference
+    x64 = x.double()
+    a64 = (F.relu(x64 * xs.double().view(1, C, 1, 1) + xsh.double().view(1, C, 1, 1)) if x_bn else x64).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    y64 = conv_rep(a64, w64)
+    z64 = F.relu(F.batch_norm(y64, None, None, gamma.double(), beta.double(), training=True, eps=1e-5))
+    (dy64,) = torch.autograd.grad((z64 * g.double()).sum(), y64, retain_graph=True)
+    ga_ref, gw_ref = torch.autograd.grad((z64 * g.double()).sum(), [a64, w64])
+    gin_ref = ga_ref + (addend.double() if with_add else 0.0)
+    # ---- device: forward conv + statistics + coefficients (as the model's schedule), then the fused backward
+    wf = torch.empty(9 * C * C, device="cuda"); wd = torch.empty(4 * 9 * C * C, device="cuda")
+    L.call("sifsr_pack_conv_weights", dev(w), C, C, wf, wd, S())
+    wwf = torch.empty(16 * C * C, device="cuda"); wwd = torch.empty(16 * C * C, device="cuda")
+    L.call("sifsr_pack_conv_weights_wino", dev(w), C, C, wwf, wwd, S())
+    dx = dev(nhwc(x))
+    dxs, dxsh = (dev(xs), dev(xsh)) if x_bn else (None, None)
+    y = torch.empty(B, H, W, C, device="cuda")
+    nblk = L.call("sifsr_conv3x3_stat_blocks", B, H, W, C)
+    part = torch.empty(nblk, C, 2, device="cuda")
+    L.call("sifsr_conv3x3_fwd", dx, C, dxs, dxsh, None, 0, None, None, wf, y, C, part, B, H, W, S())
+    mean, invstd, scale, shift = (torch.empty(C, device="cuda") for _ in range(4))
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    L.call("sifsr_bn_finalize", part, nblk, C, float(B * H * W), dev(gamma), dev(beta), rm, rv, 0.1, 1e-5, mean, invstd, scale, shift, S())
+    npix = B * H * W
+    nb = max(1, min(1024, npix // 256))
+    partials = torch.empty(max(nb, 1024) * C * 2, device="cuda")
+    dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    coef = torch.empty(3 * C, dtype=torch.float64, device="cuda")
+    coef_f = torch.empty(4 * C, device="cuda")
+    dg = dev(nhwc(g))
+    L.call("sifsr_bn_relu_bwd_coef", dg, y, scale, shift, mean, invstd, dev(beta), C, npix, partials, nb, dgam, dbet, coef, coef_f, None, H, W, S())
+    rows = L.call("sifsr_conv3x3_bwd16_stat_rows", B, H, W)
+    assert rows > 0
+    scratch = torch.empty(L.call("sifsr_conv3x3_bwd16_scratch_floats", B, H, W), device="cuda")
+    gin = torch.full((B, H, W, C), float("nan"), device="cuda")
+    dw = torch.full((C, C, 3, 3), float("nan"), device="cuda")
+    border = torch.full((B, H, W, C), float("nan"), device="cuda")
+    bnp = torch.full((rows, C, 2), float("nan"), device="cuda") if with_stats else None
+    if dyf:
+        g_arg, y_arg, c_arg, b_arg = dg, y, coef_f, border
+    else:
+        g_arg, y_arg, c_arg, b_arg = dev(nhwc(dy64.float())), None, None, None
+    L.call("sifsr_conv3x3_bwd16", dx, dxs, dxsh, g_arg, y_arg, c_arg, b_arg, wd, wwd, gin, dev(nhwc(addend)) if with_add else None,
+           dx if with_stats else None, dxs if with_stats else None, dxsh if with_stats else None, bnp, scratch, dw, B, H, W, S())
+    torch.cuda.synchronize()
+    e_gin, e_dw = rel_err(nchw(gin.cpu()), gin_ref), rel_err(dw.cpu(), gw_ref)
+    print(f"bwd16 {case}: gin {e_gin:.2e}, dw {e_dw:.2e}")
+    assert e_gin < TOL and e_dw < TOL
+    if dyf:
+        edge = torch.zeros(H, W, dtype=torch.bool); edge[0] = edge[-1] = True; edge[:, 0] = edge[:, -1] = True
+        bc = nchw(border.cpu())
+        assert torch.isnan(bc[:, :, ~edge]).all() and rel_err(bc[:, :, edge], dy64[:, :, edge]) < TOL
+    if with_stats:
+        assert x_bn
+        zpos = (x64 * xs.double().view(1, C, 1, 1) + xsh.double().view(1, C, 1, 1)) > 0
+        dz = torch.where(zpos, gin_ref, torch.zeros_like(gin_ref))
+        s_ref = torch.stack((dz.sum(dim=(0, 2, 3)), (dz * x64).sum(dim=(0, 2, 3))), dim=1)       # [C][2]
+        s_got = bnp.double().sum(dim=0).cpu()
+        assert rel_err(s_got, s_ref) < TOL, (s_got, s_ref)
+    # the separate kernels on the same operands: same results to fp32 rounding
+    gin_s = torch.full((B, H, W, C), float("nan"), device="cuda")
+    if dyf:
+        L.call("sifsr_conv3x3_dgrad_fused", dg, y, coef_f, C, wd, wwd, C, gin_s, C, None, 0, dev(nhwc(addend)) if with_add else None,
+               torch.empty_like(border), B, H, W, S())
+    else:
+        L.call("sifsr_conv3x3_dgrad_wino", g_arg, C, wd, wwd, C, gin_s, C, None, 0, None, B, H, W, S())
+    sc2 = torch.empty(L.call("sifsr_conv3x3_wgrad_wino_scratch_floats", C, C, 64), device="cuda")
+    dw_s = torch.empty(C, C, 3, 3, device="cuda")
+    L.call("sifsr_conv3x3_wgrad_wino", dx, C, dxs, dxsh, None, 0, None, None, g_arg, y_arg, c_arg, C, sc2, 64, dw_s, B, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(gin, gin_s) < 2e-6 and rel_err(dw, dw_s) < 2e-5
+
+
+def test_conv3x3_bwd16_rejects_other_shapes(L):
+    assert L.call("sifsr_conv3x3_bwd16_stat_rows", 2, 24, 32) == 0 and L.call("sifsr_conv3x3_bwd16_scratch_floats", 2, 16, 16) == 0
+    t = torch.zeros(2, 24, 32, 16, device="cuda")
+    w = torch.zeros(4 * 9 * 256, device="cuda")
+    with pytest.raises(Exception):
+        L.call("sifsr_conv3x3_bwd16", t, None, None, t, None, None, None, w, w, t, None, None, None, None, None, t, w, 2, 24, 32, S())

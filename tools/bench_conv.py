@@ -9,7 +9,7 @@ cout = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 H = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 B = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 20
-mode = sys.argv[7] if len(sys.argv) > 7 else "wino"      # wino (fp32, what the model runs) | fp32 (tap-domain kernel) | bf16 | bf16x3 (fwd / dgrad only)
+mode = sys.argv[7] if len(sys.argv) > 7 else "wino"      # wino (fp32, what the model runs) | fp32 (tap-domain kernel) | bf16
 dev = "cuda"
 torch.manual_seed(0)
 x = torch.randn(B, H, H, cin, device=dev)

@@ -10,7 +10,8 @@ followed ONE instruction later -- it read the old register; one transform-domain
 three kernel variants, everything else right.
 
 This script compiles a .hip source to gfx950 assembly and checks every inline-asm vector instruction against the MFMAs
-around it (wait states: one per instruction, N + 1 for `s_nop N`; textual order, i.e. fall-through paths):
+around it (wait states: one per instruction, N + 1 for `s_nop N`; rule A follows every control-flow path -- fall-through and
+the target of each branch met inside the window, loop back-edges included; rules B-D look back in textual order):
 
   A  asm writes a VGPR that an MFMA reads (SrcA/B/C) fewer than 2 wait states later  (VALU write -> MFMA read; LLVM pads 2 for
      instructions it knows).  VALIDATED: the failing build had three of these, every passing build none.  An ERROR.
@@ -51,8 +52,12 @@ def passes(op):
     return 2 if mm == 4 else 16 if mm == 32 else 8
 
 
+LABELS = {}   # {function: {label: instruction index}} of the last parse() call
+
+
 def parse(asm_text):
-    """-> {function: [instr]}, instr = dict(op, dst, srcs, asm, ws, line)"""
+    """-> {function: [instr]}, instr = dict(op, dst, srcs, asm, ws, line[, target]); fills LABELS"""
+    LABELS.clear()
     funcs, cur, in_asm = {}, None, False
     for ln, raw in enumerate(asm_text.splitlines(), 1):
         line = raw.strip()
@@ -68,6 +73,9 @@ def parse(asm_text):
         if m and not raw.startswith(".L") and not raw.startswith("\t"):
             cur = m.group(1)
             funcs[cur] = []
+            continue
+        if cur is not None and re.match(r"^\.L[\w.$]+:", line) and not line.startswith(".Lfunc_end"):
+            LABELS.setdefault(cur, {})[line.split(":")[0]] = len(funcs[cur])       # label -> index of the next instruction
             continue
         if cur is None or line.startswith((".", ";")) or line.endswith(":"):
             if line.startswith(".Lfunc_end"):
@@ -90,6 +98,8 @@ def parse(asm_text):
         if op == "s_nop" and toks:
             ws = int(toks[0], 0) + 1
         ins = {"op": op, "asm": in_asm, "ws": ws, "line": ln, "text": code}
+        if op.startswith(("s_cbranch", "s_branch")) and toks:
+            ins["target"] = toks[0]
         if op.startswith("v_") and toks:
             ins["dst"] = regs(toks[0])
             ins["srcs"] = [regs(t.split(" ")[0]) for t in toks[1:]]
@@ -106,14 +116,26 @@ def lint_function(name, instrs):
             continue
         rd = set().union(*ins["srcs"]) if ins["srcs"] else set()
         wr = ins["dst"]
-        # forward: rule A
-        gap = 0
-        for nxt in instrs[i + 1:]:
-            if gap >= 2:
-                break
-            if nxt["op"].startswith("v_mfma") and wr & set().union(*nxt["srcs"]):
-                findings.append((name, ins["line"], "A", f"{ins['text']}  ->  {nxt['text']} ({gap} wait states)"))
-            gap += nxt["ws"]
+        # forward: rule A, along EVERY control-flow path of the next two wait states: fall-through, and the target of each
+        # branch met on the way (conditional: both ways; s_branch: the target only) -- loop back-edges included
+        labels = LABELS.get(name, {})
+        stack, seen = [(i + 1, 0)], set()
+        while stack:
+            j, gap = stack.pop()
+            while j < len(instrs) and gap < 2 and (j, gap) not in seen:
+                seen.add((j, gap))
+                nxt = instrs[j]
+                if nxt["op"].startswith("v_mfma") and wr & set().union(*nxt["srcs"]):
+                    findings.append((name, ins["line"], "A", f"{ins['text']}  ->  {nxt['text']} ({gap} wait states)"))
+                gap += nxt["ws"]
+                if "target" in nxt:
+                    if nxt["target"] in labels:
+                        stack.append((labels[nxt["target"]], gap))
+                    if nxt["op"].startswith("s_branch"):
+                        break
+                if nxt["op"] in ("s_endpgm", "s_setpc_b64"):
+                    break
+                j += 1
         # backward: rules B, C, D
         gap = 0
         for prv in reversed(instrs[:i]):
