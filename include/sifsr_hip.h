@@ -156,6 +156,8 @@ SIFSR_API int sifsr_conv3x3_wgrad_bf16(const float* src0, int C0, const float* s
                                   const float* dy, int cout, float* scratch, int nblk, float* dw, int B, int H, int W,
                                   void* stream);
 /* inbloc.bloc.0, Conv2d(2,16): x NCHW -> y NHWC (model.py:596) */
+/* stat_partials: NULL or [sifsr_conv_in_stat_blocks()][16][2] per-workgroup (sum, sumsq) of y */
+SIFSR_API int sifsr_conv_in_stat_blocks(int B, int H, int W);
 SIFSR_API int sifsr_conv_in_fwd(const float* x, const float* w, float* y, float* stat_partials, int B, int H, int W, void* stream);
 SIFSR_API int sifsr_conv_in_wgrad(const float* x, const float* dy, float* scratch, int nblk, float* dw, int B, int H, int W, void* stream);
 /* outlay, Conv2d(16,1)+bias: y NHWC (BN+ReLU folded) -> sr NCHW (model.py:605); dwb = [144 weight | 1 bias] */

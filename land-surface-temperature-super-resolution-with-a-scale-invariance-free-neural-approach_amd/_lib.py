@@ -86,7 +86,7 @@ def call(name: str, *args):
     """Call a C-ABI function; tensors are passed as device pointers.  Raises on a non-zero status."""
     fn = getattr(lib(), name)
     rc = fn(*[_conv(a) for a in args])
-    if fn.restype is ctypes.c_int and rc != 0 and not name.startswith(("sifsr_abi", "sifsr_num", "sifsr_layer", "sifsr_huber_partial", "sifsr_model_workspace_regions", "sifsr_conv3x3_stat", "sifsr_conv3x3_bwd16_stat", "sifsr_profile_add", "sifsr_up2x_bwd_stat")):
+    if fn.restype is ctypes.c_int and rc != 0 and not name.startswith(("sifsr_abi", "sifsr_num", "sifsr_layer", "sifsr_huber_partial", "sifsr_model_workspace_regions", "sifsr_conv3x3_stat", "sifsr_conv_in_stat", "sifsr_conv3x3_bwd16_stat", "sifsr_profile_add", "sifsr_up2x_bwd_stat")):
         raise SifsrError(f"{name} failed with status {rc}")
     return rc
 

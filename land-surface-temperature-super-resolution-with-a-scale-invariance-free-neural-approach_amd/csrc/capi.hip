@@ -272,7 +272,7 @@ int sifsr_conv3x3_bwd16_stat_rows(int B, int H, int W) {
   return conv3x3_bwd16_applies(B, H, W) ? conv3x3_bwd16_grid(B, H, W) + dgrad_border_waves(B, H, W, 16) : 0;
 }
 size_t sifsr_conv3x3_bwd16_scratch_floats(int B, int H, int W) {
-  return conv3x3_bwd16_applies(B, H, W) ? ((size_t)4 * conv3x3_bwd16_grid(B, H, W) + 2) * 16 * 256 : 0;
+  return conv3x3_bwd16_applies(B, H, W) ? ((size_t)conv3x3_bwd16_grid(B, H, W) + 2) * 16 * 256 : 0;
 }
 int sifsr_conv3x3_bwd16(const float* x, const float* x_scale, const float* x_shift, const float* g, const float* y,
                         const float* coef_f, float* border, const float* wdgrad, const float* wwd, float* gin,
@@ -295,8 +295,8 @@ int sifsr_conv3x3_bwd16(const float* x, const float* x_scale, const float* x_shi
                                bn_partials ? bn_partials + (size_t)grid * 32 : nullptr);
   if (rc) return rc;
   WgradReduceJob j;
-  j.slab_off = 0; j.nblk = 4 * grid; j.cin = 16; j.cout = 16; j.nbi_chunk = 1; j.w_off = 0;
-  return launch_wgrad_wino_finish(scratch, &j, 1, reinterpret_cast<double*>(scratch + (size_t)4 * grid * 16 * 256), dw, S(stream));
+  j.slab_off = 0; j.nblk = grid; j.cin = 16; j.cout = 16; j.nbi_chunk = 1; j.w_off = 0;
+  return launch_wgrad_wino_finish(scratch, &j, 1, reinterpret_cast<double*>(scratch + (size_t)grid * 16 * 256), dw, S(stream));
 }
 
 // bf16-operand form (config 5): x and dy rounded to bf16 when read from LDS, fp32 accumulation
@@ -318,6 +318,7 @@ int sifsr_conv3x3_wgrad_bf16(const float* src0, int C0, const float* scale0, con
   return launch_wgrad_reduce(scratch, nblk, cin, cout, wgrad_nbi_chunk(a, cin), dw, S(stream));
 }
 
+int sifsr_conv_in_stat_blocks(int B, int H, int W) { return conv_in_fwd_blocks(B, H, W); }
 int sifsr_conv_in_fwd(const float* x, const float* w, float* y, float* stat_partials, int B, int H, int W, void* stream) {
   return launch_conv_in_fwd(x, w, y, stat_partials, B, H, W, S(stream));
 }

@@ -106,12 +106,12 @@ struct Bwd16Args {
   const float* bn_scale = nullptr; //   layer's BatchNorm-backward sums (sum dz, sum dz * y per channel) ...
   const float* bn_shift = nullptr;
   float* stat_partials = nullptr;  // ... as [conv3x3_bwd16_grid()][16][2]
-  float* slabs;                    // out: 4 * conv3x3_bwd16_grid() weight-gradient slabs of 16 * 256 floats (Winograd domain,
-                                   //   the layout of conv_wgrad_wino.hip; reduce with launch_wgrad_wino_finish, nblk = 4 * grid)
+  float* slabs;                    // out: conv3x3_bwd16_grid() weight-gradient slabs of 16 * 256 floats (Winograd domain,
+                                   //   the layout of conv_wgrad_wino.hip; reduce with launch_wgrad_wino_finish, nblk = grid)
   int B, H, W;
 };
 bool conv3x3_bwd16_applies(int B, int H, int W);
-int conv3x3_bwd16_grid(int B, int H, int W);           // workgroups launched = stat_partials rows; 4 slabs each
+int conv3x3_bwd16_grid(int B, int H, int W);           // workgroups launched = stat_partials rows = slabs
 int launch_conv3x3_bwd16(const Bwd16Args& a, hipStream_t s);
 
 // dgrad: replicate-padding adjoint fold for the border pixels (adds to g_in).  wdg_layer = the layer's

@@ -14,11 +14,11 @@
 //              layer below (its y requested before the MFMAs);
 //   waves 4-7  weight gradient, Winograd F(3x3,2x2): the per-lane register transforms of conv_wgrad_wino.hip (lane = (channel,
 //              patch of a 4-patch k-step); 2 + 8 ds_read_b64 from channel planes, 16 MFMAs per k-step, 4 k-steps per wave and
-//              tile), accumulators live across all tiles, one slab per wave at the end.
+//              tile), accumulators live across all tiles, added up through LDS into one slab per workgroup at the end.
 // One of each role per SIMD: the two MFMA streams (64 MFMAs per wave and tile each) interleave on the matrix pipe and each
 // role's transform / epilogue instructions issue under the other's MFMAs.  All eight waves stage: thread = (channel quad,
 // 3 of the 324 halo pixels), the next tile's 9 float4 loads in flight during the contraction, LDS double-buffered -> ONE barrier
-// per tile.  The replicate-border fold of the input gradient stays the separate kernel (dgrad_border_kernel).
+// per tile, and the two roles stage at different times (see tile_loop).  The replicate-border fold of the input gradient stays the separate kernel (dgrad_border_kernel).
 #include "conv.h"
 
 #include <stdlib.h>
@@ -194,24 +194,43 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
   // The tile loop, instantiated once per role (two loops, not one loop with a role branch inside: the weight-gradient
   // accumulators are then live only in the weight-gradient waves' code and the input-gradient waves' transforms do not spill).
   // Both roles execute exactly one barrier per tile, so the workgroup's barrier counts match.
-  auto tile_loop = [&](auto&& contract) {
+  // The two roles of a SIMD are OUT OF PHASE: the input-gradient waves stage their share of tile j+1 BEFORE they contract
+  // tile j, the weight-gradient waves after -- each role's staging (vector / LDS instructions) issues under the other role's
+  // MFMAs instead of both staging while the matrix pipe idles (conv_wino8.hip does the same with its two wave teams).
+  //   iteration j:   A: stage(j+1) -> loads(j+2) -> contract(j) -> barrier      B: contract(j) -> stage(j+1) -> loads(j+2) -> barrier
+  // The barrier of iteration j publishes tile j+1 (other buffer) and retires every read of tile j's buffer.
+  auto tile_loop = [&](const bool stage_first, auto&& contract) {
     int t = t_first, buf = 0;
-    if (t < t_hi) issue(t);
+    if (t >= t_hi) { __syncthreads(); return; }           // (wlds barrier; workgroups without tiles exist only for tiny problems)
+    issue(t);
     __syncthreads();                                      // wlds
-    while (t < t_hi) {
-      write_stage(buf);
-      const int cb = st_b, txi = st_tx, tyi = st_ty;      // the tile being contracted
+    write_stage(0);
+    int cb = st_b, txi = st_tx, tyi = st_ty;              // the tile being contracted
+    if (t + t_step < t_hi) issue(t + t_step);
+    __syncthreads();                                      // tile 0 staged
+    while (true) {
       const int t_next = t + t_step;
-      if (t_next < t_hi) issue(t_next);                   // in flight during the contraction below
-      __syncthreads();                                    // tile staged (and everybody is past the previous use of the other buffer)
+      const bool more = t_next < t_hi;
+      const int nb_ = st_b, ntx_ = st_tx, nty_ = st_ty;   // position of tile j+1 (in flight)
+      if (stage_first && more) {
+        write_stage(buf ^ 1);
+        if (t_next + t_step < t_hi) issue(t_next + t_step);
+      }
       contract(buf, cb, txi, tyi);
+      if (!stage_first && more) {
+        write_stage(buf ^ 1);
+        if (t_next + t_step < t_hi) issue(t_next + t_step);
+      }
+      if (!more) break;
+      __syncthreads();
+      cb = nb_; txi = ntx_; tyi = nty_;
       t = t_next;
       buf ^= 1;
     }
   };
 
   if (dgrad_role) {
-    tile_loop([&](const int buf, const int cb, const int txi, const int tyi) {
+    tile_loop(true, [&](const int buf, const int cb, const int txi, const int tyi) {
       // ======================= input gradient: Winograd F(2x2,3x3), one 16-patch group (4 tile rows) per wave =======================
       float4 yq[4];
       if (bn_stats) {
@@ -291,11 +310,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
         }
       }
     });
+    for (int w = 0; w < 7; ++w) __syncthreads();          // the weight-gradient waves' slab reduction (below): 1 + 3 * 2 barriers
   } else {
     f32x4 acc[16];
 #pragma unroll
     for (int tt = 0; tt < 16; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    tile_loop([&](const int buf, const int cb, const int txi, const int tyi) {
+    tile_loop(false, [&](const int buf, const int cb, const int txi, const int tyi) {
       (void)cb; (void)txi; (void)tyi;
       // ======================= weight gradient: Winograd F(3x3,2x2), 4 k-steps (of 4 patches) per wave =======================
       const float* const pa = dyp[buf] + pa_off;
@@ -334,10 +354,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
         for (int tt = 0; tt < 16; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ug[tt], vv[tt], acc[tt], 0, 0, 0);
       }
     });
-    // ---- weight-gradient slabs: one per weight-gradient wave, [xi][lane][4] (the layout of conv_wgrad_wino.hip for one block pair)
-    float* slab = a.slabs + ((size_t)blockIdx.x * 4 + wave) * (16 * 256);
+    // ---- the four weight-gradient waves' accumulators are added up through LDS in a fixed order (waves 1, 2, 3 into wave 0;
+    // the input-gradient waves execute the matching barriers), then ONE slab per workgroup, [xi][lane][4] (the layout of
+    // conv_wgrad_wino.hip for one block pair)
+    float4* const comb = dyq[0];
+    __syncthreads();                                      // every read of the tile buffers is done
+    for (int w = 1; w < 4; ++w) {
+      if (wave == w) {
 #pragma unroll
-    for (int tt = 0; tt < 16; ++tt) st4(slab + tt * 256 + lane * 4, make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]));
+        for (int tt = 0; tt < 16; ++tt) comb[tt * 64 + lane] = make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) { const float4 v = comb[tt * 64 + lane]; acc[tt][0] += v.x; acc[tt][1] += v.y; acc[tt][2] += v.z; acc[tt][3] += v.w; }
+      }
+      __syncthreads();
+    }
+    if (wave == 0) {
+      float* slab = a.slabs + (size_t)blockIdx.x * (16 * 256);
+#pragma unroll
+      for (int tt = 0; tt < 16; ++tt) st4(slab + tt * 256 + lane * 4, make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]));
+    }
   }
   // ---- BatchNorm-backward partials of the layer below: one row per workgroup
   if (a.stat_partials != nullptr) {

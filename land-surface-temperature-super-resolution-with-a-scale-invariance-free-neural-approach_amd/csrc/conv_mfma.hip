@@ -855,7 +855,6 @@ __global__ __launch_bounds__(256, 8) void dgrad_border_kernel(const float* __res
   if (r < 2 * seg_tb) { side = r / seg_tb; seg = r - side * seg_tb; }
   else { r -= 2 * seg_tb; side = 2 + r / seg_lr; seg = r % seg_lr; }
   const int px = lane & 15, kq = lane >> 4;
-  const float* img = dy + (size_t)b * H * W * Cout;
   const float* wbase = wd + (size_t)nb * NQ * 9 * 256 + lane * 4;       // wd[nb][q][tap'][lane][4]
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);

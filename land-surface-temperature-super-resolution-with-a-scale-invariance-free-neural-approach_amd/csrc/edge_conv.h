@@ -4,6 +4,7 @@
 #include "common.h"
 
 // ---- edge_conv.hip ----
+int conv_in_fwd_blocks(int B, int H, int W);   // rows of `partials` ([blocks][16][2]) launch_conv_in_fwd writes
 int launch_conv_in_fwd(const float* x, const float* w, float* y, float* partials, int B, int H, int W, hipStream_t s);
 int launch_conv_in_wgrad(const float* x, const float* dy, float* partials, int nblk, float* dw, int B, int H, int W, hipStream_t s);
 int launch_conv_out_fwd(const float* y, const float* scale, const float* shift, const float* w, const float* bias,

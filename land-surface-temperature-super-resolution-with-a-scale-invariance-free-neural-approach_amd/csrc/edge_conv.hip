@@ -17,18 +17,25 @@ namespace {
 // write floor.)
 __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           float* __restrict__ y, float* __restrict__ partials,
-                                                          int H, int W) {
-  __shared__ float tile[2 * 324];
+                                                          int B, int H, int W) {
+  // PERSISTENT since round 3: conv_in_fwd_blocks() workgroups walk the 16x16 tiles, so the BatchNorm statistics come out as
+  // <= 2048 partial rows instead of one per tile (16,384 at batch 64: the finalize launch behind it took 28 us, now 7)
+  __shared__ float tile[2][2 * 324];
   __shared__ float red[4][16][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16, b = blockIdx.z;
-  for (int e = tid; e < 2 * 324; e += 256) {
-    const int c = e / 324, p = e - c * 324;
-    const int py = p / 18, px = p - py * 18;
-    const int gy = clampi(y0 - 1 + py, 0, H - 1), gx = clampi(x0 - 1 + px, 0, W - 1);
-    tile[e] = x[((size_t)(b * 2 + c) * H + gy) * W + gx];
-  }
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16, ntiles = B * tiles_x * tiles_y;
+  auto stage = [&](int t, float* dst) {
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+    const int x0 = tx * 16, y0 = ty * 16;
+    for (int e = tid; e < 2 * 324; e += 256) {
+      const int c = e / 324, p = e - c * 324;
+      const int py = p / 18, px = p - py * 18;
+      const int gy = clampi(y0 - 1 + py, 0, H - 1), gx = clampi(x0 - 1 + px, 0, W - 1);
+      dst[e] = x[((size_t)(b * 2 + c) * H + gy) * W + gx];
+    }
+  };
+  if ((int)blockIdx.x < ntiles) stage(blockIdx.x, tile[0]);
   float wa[5];      // A[co = i][k = 4j + kq]: w is OIHW = [co][ci*9 + t]; k >= 18 is padding (weight 0, any finite B)
   int off[5];       // B[k][px = i]: plane ci, tap (t/3, t%3) of the halo tile, row added per MFMA
 #pragma unroll
@@ -38,19 +45,26 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
     const int c = kk >= 9 ? 1 : 0, t = kk < 18 ? kk - 9 * c : 0;
     off[j] = (kk < 18 ? c * 324 : 0) + (t / 3) * 18 + t % 3 + i;
   }
-  __syncthreads();
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  int buf = 0;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x, buf ^= 1) {
+    __syncthreads();                                   // tile[buf] staged; everybody is past the previous use of tile[buf ^ 1]
+    if (t + (int)gridDim.x < ntiles) stage(t + gridDim.x, tile[buf ^ 1]);
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+    const int x0 = tx * 16, y0 = ty * 16;
+    const float* T = tile[buf];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = 4 * wave + r;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * wave + r;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 5; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], tile[off[j] + row * 18], acc, 0, 0, 0);
-    // lane: output channels 4*kq .. 4*kq+3 of pixel (row, i); partial tiles when H or W is not a multiple of 16
-    if (y0 + row < H && x0 + i < W) {
-      st4(y + ((size_t)(b * H + y0 + row) * W + x0 + i) * 16 + 4 * kq, make_float4(acc[0], acc[1], acc[2], acc[3]));
+      for (int j = 0; j < 5; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], T[off[j] + row * 18], acc, 0, 0, 0);
+      // lane: output channels 4*kq .. 4*kq+3 of pixel (row, i); partial tiles when H or W is not a multiple of 16
+      if (y0 + row < H && x0 + i < W) {
+        st4(y + ((size_t)(b * H + y0 + row) * W + x0 + i) * 16 + 4 * kq, make_float4(acc[0], acc[1], acc[2], acc[3]));
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { s1[q] += acc[q]; s2[q] = fmaf(acc[q], acc[q], s2[q]); }
+        for (int q = 0; q < 4; ++q) { s1[q] += acc[q]; s2[q] = fmaf(acc[q], acc[q], s2[q]); }
+      }
     }
   }
   if (partials != nullptr) {
@@ -64,8 +78,7 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
     if (tid < 32) {
       const int co = tid >> 1, j = tid & 1;
       const float s = red[0][co][j] + red[1][co][j] + red[2][co][j] + red[3][co][j];
-      const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      partials[(blk * 16 + co) * 2 + j] = s;
+      partials[((size_t)blockIdx.x * 16 + co) * 2 + j] = s;
     }
   }
 }
@@ -333,9 +346,14 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 
 }  // namespace
 
+int conv_in_fwd_blocks(int B, int H, int W) {   // workgroups launched == statistic rows written
+  const int ntiles = B * ((H + 15) / 16) * ((W + 15) / 16);
+  return ntiles < 2048 ? ntiles : 2048;
+}
+
 int launch_conv_in_fwd(const float* x, const float* w, float* y, float* partials, int B, int H, int W, hipStream_t s) {
-  if (H < 1 || W < 1) return SIFSR_ERR_SHAPE;
-  hipLaunchKernelGGL(conv_in_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16, B), dim3(256), 0, s, x, w, y, partials, H, W);
+  if (H < 1 || W < 1 || B < 1) return SIFSR_ERR_SHAPE;
+  hipLaunchKernelGGL(conv_in_fwd_kernel, dim3(conv_in_fwd_blocks(B, H, W)), dim3(256), 0, s, x, w, y, partials, B, H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

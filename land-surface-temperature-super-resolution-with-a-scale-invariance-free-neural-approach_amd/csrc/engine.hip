@@ -134,9 +134,9 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
       // ... and over the two kernel families: the tap-domain grid scales with SIFSR_DBG_WGRAD_GRID_PCT, the Winograd one does not
       const int nb_tap = wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles, false), nb_wino = wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles, true);
       w.slab_cap[l] = (size_t)(nb_tap > nb_wino ? nb_tap : nb_wino) * 16 * nt.L[l].cin * nt.L[l].cout;
-      // ... and the fused input + weight gradient kernel of the 16 -> 16 layers writes one slab per weight-gradient wave
+      // ... and the fused input + weight gradient kernel of the 16 -> 16 layers writes one slab per workgroup
       if (nt.L[l].cin == 16 && nt.L[l].cout == 16 && conv3x3_bwd16_applies(B, lvh, lvw)) {
-        const size_t need = (size_t)4 * conv3x3_bwd16_grid(B, lvh, lvw) * 16 * 256;
+        const size_t need = (size_t)conv3x3_bwd16_grid(B, lvh, lvw) * 16 * 256;
         if (need > w.slab_cap[l]) w.slab_cap[l] = need;
       }
       w.slab_l[l] = take(w.slab_cap[l]);
@@ -470,7 +470,7 @@ int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin
     return SIFSR_OK;
   const bool fuse = bn_layer >= 0 && addend == nullptr && c.nt.L[bn_layer].cout == 16 && c.nt.L[bn_layer].level == L.level;
   const int grid = conv3x3_bwd16_grid(c.B, lh, lw);
-  if ((size_t)4 * grid * 16 * 256 > c.lay.slab_cap[l] || (fuse && (size_t)grid * 32 > c.lay.partials_cap)) return SIFSR_ERR_WORKSPACE;
+  if ((size_t)grid * 16 * 256 > c.lay.slab_cap[l] || (fuse && (size_t)grid * 32 > c.lay.partials_cap)) return SIFSR_ERR_WORKSPACE;
   Bwd16Args a;
   a.x = s0.ptr; a.x_scale = s0.scale; a.x_shift = s0.shift;
   a.g = dy;
@@ -492,7 +492,7 @@ int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin
                                     fuse ? a.bn_y : nullptr, fuse ? a.bn_scale : nullptr, fuse ? a.bn_shift : nullptr,
                                     fuse ? c.f(c.lay.bpart) : nullptr));
   WgradReduceJob& j = c.xjobs[(*c.nxjobs)++];
-  j.slab_off = c.lay.slab_l[l]; j.nblk = 4 * grid; j.cin = 16; j.cout = 16; j.nbi_chunk = 1; j.w_off = L.w_off;
+  j.slab_off = c.lay.slab_l[l]; j.nblk = grid; j.cin = 16; j.cout = 16; j.nbi_chunk = 1; j.w_off = L.w_off;
   if (c.side != nullptr && hipEventRecord(c.side->ev[l], c.s) != hipSuccess) return SIFSR_ERR_ARG;   // slabs of l complete
   *applied = true;
   return SIFSR_OK;
@@ -530,7 +530,7 @@ int sifsr_engine_forward(const float* x, float* sr, const float* params, float* 
     const LayerInfo& L = nt.L[L_IN0];
     SIFSR_TRY(launch_conv_in_fwd(x, params + L.w_off, c.f(w.y[L_IN0]), training ? c.f(w.partials) : nullptr, B, H, W, s));
     if (training)
-      SIFSR_TRY(launch_bn_finalize(c.f(w.partials), B * ((H + 15) / 16) * ((W + 15) / 16), 16, (double)B * H * W, params + L.gamma_off,
+      SIFSR_TRY(launch_bn_finalize(c.f(w.partials), conv_in_fwd_blocks(B, H, W), 16, (double)B * H * W, params + L.gamma_off,
                                    params + L.beta_off, running + L.run_off, running + L.run_off + 16, momentum, eps,
                                    c.f(w.mean) + L.ch_off, c.f(w.invstd) + L.ch_off, c.f(w.scale) + L.ch_off,
                                    c.f(w.shift) + L.ch_off, s));

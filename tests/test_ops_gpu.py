@@ -179,7 +179,8 @@ def test_conv_in(L, shape):
     dy = rnd(rs, B, 16, H, W)
     (gw_ref,) = torch.autograd.grad((y_ref * dy).sum(), [w])
     y = torch.empty(B, H, W, 16, device="cuda")
-    nblk = B * ((H + 15) // 16) * ((W + 15) // 16)
+    nblk = L.call("sifsr_conv_in_stat_blocks", B, H, W)
+    assert nblk == min(2048, B * ((H + 15) // 16) * ((W + 15) // 16))
     part = torch.empty(nblk, 16, 2, device="cuda")
     L.call("sifsr_conv_in_fwd", dev(x), dev(w.detach()), y, part, B, H, W, S())
     torch.cuda.synchronize()

@@ -8,6 +8,6 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 if [ "$2" = "single" ]; then export SIFSR_WGRAD_STREAM=0; fi
-CMD="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-solo"
+CMD="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-solo --no-also"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1 || exit 1
 tail -1 $OUT/stats.log | cut -c1-200
