@@ -24,14 +24,16 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra=(), lib=None, obj_dir=None):
-    """lib / obj_dir: build a VARIANT of the library elsewhere (tools/build_ab.sh: same-device A/B through SIFSR_LIB)."""
+def build(force=False, verbose=False, extra=(), lib=None, obj_dir=None, csrc=None):
+    """lib / obj_dir / csrc: build a VARIANT of the library elsewhere, optionally from another source tree (tools/build_ab.sh,
+    tools/build_ref.sh: same-device A/B through SIFSR_LIB)."""
     LIB_ = lib or LIB
     OBJ_ = obj_dir or OBJ
+    CSRC = csrc or globals()["CSRC"]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "sifsr_hip.h"))
+    hdrs.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "sifsr_hip.h"))
     os.makedirs(OBJ_, exist_ok=True)
     jobs = []
     for f in srcs:

@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 
 // Same, for sums produced by the dgrad epilogue + border kernel of the layer above (conv_mfma.hip): two partial arrays,
 // and the second sum is sum dz*y (not dz*xhat): sum dz*xhat = invstd * (sum dz*y - mean * sum dz), in float64.
-__global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __restrict__ pa, int na,
+template <int NT>   // threads per channel: 1024 when there are thousands of partial rows (the upsample adjoint writes one per 8x8 pixels)
+__global__ __launch_bounds__(NT) void bn_bwd_finalize2_kernel(const float* __restrict__ pa, int na,
                                                                const float* __restrict__ pb, int nb, int C, double count,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ mean,
@@ -184,14 +185,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const float* __re
                                                                float* dbeta, double* coef, const float* __restrict__ shift,
                                                                const float* __restrict__ beta, float* coef_f) {
   SIFSR_CHAIN_PRIO();
-  __shared__ double r1[256], r2[256];
+  __shared__ double r1[NT], r2[NT];
   const int c = blockIdx.x, tid = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = tid; k < na; k += 256) { s1 += (double)pa[((size_t)k * C + c) * 2]; s2 += (double)pa[((size_t)k * C + c) * 2 + 1]; }
-  for (int k = tid; k < nb; k += 256) { s1 += (double)pb[((size_t)k * C + c) * 2]; s2 += (double)pb[((size_t)k * C + c) * 2 + 1]; }
+  for (int k = tid; k < na; k += NT) { s1 += (double)pa[((size_t)k * C + c) * 2]; s2 += (double)pa[((size_t)k * C + c) * 2 + 1]; }
+  for (int k = tid; k < nb; k += NT) { s1 += (double)pb[((size_t)k * C + c) * 2]; s2 += (double)pb[((size_t)k * C + c) * 2 + 1]; }
   r1[tid] = s1; r2[tid] = s2;
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
+  for (int st = NT / 2; st > 0; st >>= 1) {
     if (tid < st) { r1[tid] += r1[tid + st]; r2[tid] += r2[tid + st]; }
     __syncthreads();
   }
@@ -292,8 +293,13 @@ int launch_bn_bwd_finalize2(const float* pa, int na, const float* pb, int nb, in
                             const float* mean, const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s,
                             const float* shift, const float* beta, float* coef_f) {
   if (coef_f != nullptr && (!shift || !beta)) return SIFSR_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3(C), dim3(256), 0, s, pa, na, pb, nb, C, count, scale, mean, invstd, dgamma,
-                     dbeta, coef, shift, beta, coef_f);
+  // NOTE: the result depends on the thread count (summation order), so the choice is a function of the row count alone
+  if (na + nb > 4096)
+    hipLaunchKernelGGL((bn_bwd_finalize2_kernel<1024>), dim3(C), dim3(1024), 0, s, pa, na, pb, nb, C, count, scale, mean, invstd, dgamma,
+                       dbeta, coef, shift, beta, coef_f);
+  else
+    hipLaunchKernelGGL((bn_bwd_finalize2_kernel<256>), dim3(C), dim3(256), 0, s, pa, na, pb, nb, C, count, scale, mean, invstd, dgamma,
+                       dbeta, coef, shift, beta, coef_f);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
