@@ -52,11 +52,13 @@ SIFSR_API int sifsr_model_forward(const float* x, float* sr, const float* params
 SIFSR_API int sifsr_model_backward(const float* x, const float* dsr, const float* params, float* grads,
                                    void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
 /* The same two calls with a compute mode: 0 = fp32 (identical to the calls above), 1 = BASELINE.json config 5,
- * "bf16 mixed precision, MFMA-bf16 conv tiles": the operands of the sixteen 3x3 MFMA convs (activations after
- * BatchNorm+ReLU, weights, and dy in the input-gradient pass) are rounded to bf16 while staging and contracted with
- * v_mfma_f32_16x16x32_bf16, two taps per MFMA (the weight-gradient pass rounds x and dy the same way and uses the K = 16
- * form over 16 pixels); accumulation, stored
- * activations, BatchNorm, the two thin convs and the parameters stay fp32.  Forward and backward of one step must use the same mode. */
+ * "bf16 mixed precision, MFMA-bf16 conv tiles": every activation-like tensor INSIDE the network (raw conv outputs, pooled /
+ * residual / upsampled tensors and the gradients with respect to them) is STORED as bf16 -- half the HBM bytes of every pass --
+ * and the operands of the sixteen 3x3 MFMA convs (activations after BatchNorm+ReLU, weights, dy) are rounded to bf16 while
+ * staging and contracted with v_mfma_f32_16x16x32_bf16, two taps per MFMA (the weight-gradient pass uses the K = 16 form over 16
+ * pixels).  Accumulation, BatchNorm statistics and coefficients, the arithmetic of every non-conv kernel, x, sr, dsr, master
+ * weights, gradients of the parameters and the optimizer stay fp32.  The workspace size is that of the fp32 mode (the bf16
+ * tensors use the first half of their regions).  Forward and backward of one step must use the same mode. */
 SIFSR_API int sifsr_model_forward_ex(const float* x, float* sr, const float* params, float* running, long long* nbt,
                                      void* workspace, size_t workspace_bytes, int B, int H, int W, int training,
                                      float momentum, float eps, int compute, void* stream);
@@ -103,9 +105,12 @@ SIFSR_API int sifsr_conv3x3_fwd_wino(const float* src0, int C0, const float* sca
 SIFSR_API int sifsr_conv3x3_dgrad_wino(const float* dy, int cout, const float* wdgrad, const float* wwd, int cin,
                                        float* g0, int C0, float* g1, int C1, const float* addend, int B, int H, int W,
                                        void* stream);
-/* bf16-operand forms of the two calls above (BASELINE.json config 5): operands rounded to bf16 while staging,
- * v_mfma_f32_16x16x32_bf16 (two taps per MFMA), fp32 accumulation and output.  Both take the `wdgrad` buffer of
- * sifsr_pack_conv_weights, whose second half holds the bf16 fragment packs [forward | dgrad]. */
+/* bf16 forms of the two calls above (BASELINE.json config 5, "bf16 mixed precision, MFMA-bf16 conv tiles"): every activation
+ * tensor (src*, y, dy, g*, addend) is NHWC **bf16** -- the pointers are typed float* only for uniformity of the interface --,
+ * values are widened on load, the folded BatchNorm+ReLU is applied in fp32, operands are rounded to bf16 for
+ * v_mfma_f32_16x16x32_bf16 (two taps per MFMA), accumulation is fp32 and results are rounded to bf16 on store (statistics
+ * are those of the rounded values).  Both take the `wdgrad` buffer of sifsr_pack_conv_weights, whose second half holds
+ * the bf16 fragment packs [forward | dgrad]; scale / shift / stat_partials stay fp32. */
 SIFSR_API int sifsr_conv3x3_fwd_bf16(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1,
                                      int C1, const float* scale1, const float* shift1, const float* wdgrad, float* y,
                                      int cout, float* stat_partials, int B, int H, int W, void* stream);
@@ -149,13 +154,19 @@ SIFSR_API int sifsr_conv3x3_bwd16(const float* x, const float* x_scale, const fl
                                   const float* coef_f, float* border, const float* wdgrad, const float* wwd, float* gin,
                                   const float* addend, const float* bn_y, const float* bn_scale, const float* bn_shift,
                                   float* bn_partials, float* scratch, float* dw, int B, int H, int W, void* stream);
-/* bf16-operand form of the weight gradient (BASELINE.json config 5): the staged x and dy are rounded to bf16 when
- * read from LDS and contracted 16 pixels at a time with v_mfma_f32_16x16x16_bf16; fp32 accumulation and slabs. */
+/* bf16 form of the weight gradient (BASELINE.json config 5): src* and dy are NHWC bf16 tensors; the staged x and dy are
+ * rounded to bf16 when read from LDS and contracted 16 pixels at a time with v_mfma_f32_16x16x16_bf16; fp32 accumulation,
+ * slabs and dw. */
 SIFSR_API int sifsr_conv3x3_wgrad_bf16(const float* src0, int C0, const float* scale0, const float* shift0,
                                   const float* src1, int C1, const float* scale1, const float* shift1,
                                   const float* dy, int cout, float* scratch, int nblk, float* dw, int B, int H, int W,
                                   void* stream);
 /* inbloc.bloc.0, Conv2d(2,16): x NCHW -> y NHWC (model.py:596) */
+/* Activation storage of the single-operator entry points below that are not 3x3 convolutions (the thin first / last convs,
+ * BatchNorm reductions, pooling / upsampling and their adjoints, the fused tail): on = 1 makes the calling thread's later calls
+ * treat their activation tensors (y, g, dy, pooled / upsampled tensors; NOT x, sr, dsr, parameters, statistics) as NHWC bf16,
+ * as ModelB_2's bf16 mode does; 0 (default) = fp32.  sifsr_model_forward_ex / _backward_ex choose it from `compute`. */
+SIFSR_API int sifsr_set_op_storage_bf16(int on);
 /* stat_partials: NULL or [sifsr_conv_in_stat_blocks()][16][2] per-workgroup (sum, sumsq) of y */
 SIFSR_API int sifsr_conv_in_stat_blocks(int B, int H, int W);
 SIFSR_API int sifsr_conv_in_fwd(const float* x, const float* w, float* y, float* stat_partials, int B, int H, int W, void* stream);

@@ -64,17 +64,17 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ params, const fl
 // (the skip layers inbloc.bloc.3 / db1,2.lastconv feed both the decoder skip and the next pooling stage; this
 // replaces a separate read-modify-write pass over g).  W2 = W/2 etc. describe the full-resolution image.
 struct PoolAdj { const float* gp; int H, W; };
-template <int C>
+template <int C, bool HS = false>
 __device__ __forceinline__ float4 pool_adj4(const PoolAdj pa, size_t p, int c4) {
   const unsigned W = (unsigned)pa.W, H = (unsigned)pa.H;
   const unsigned x = (unsigned)(p % W), r = (unsigned)(p / W);
   const unsigned yy = r % H, b = r / H;
-  const float4 v = ld4(pa.gp + (((size_t)b * (H / 2) + yy / 2) * (W / 2) + x / 2) * C + 4 * c4);
+  const float4 v = ldA4<HS>(pa.gp, (((size_t)b * (H / 2) + yy / 2) * (W / 2) + x / 2) * C + 4 * c4);
   return make_float4(0.25f * v.x, 0.25f * v.y, 0.25f * v.z, 0.25f * v.w);
 }
 
 // per-workgroup partial (sum dz, sum dz*xhat) per channel
-template <int C>
+template <int C, bool HS>   // HS: g, y, gp stored as bf16 (the bf16 compute mode, common.h)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* g, const float* __restrict__ y,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
@@ -90,13 +90,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* g, cons
   const float4 sc = ld4(scale + 4 * c4), sh = ld4(shift + 4 * c4), mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4);
   double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
   for (size_t p = (size_t)blockIdx.x * PP + pl; p < npix; p += (size_t)gridDim.x * PP) {
-    const float4 yv = ld4(y + p * C + 4 * c4);
-    float4 gv = ld4(g + p * C + 4 * c4);
+    const float4 yv = ldA4<HS>(y, p * C + 4 * c4);
+    float4 gv = ldA4<HS>(g, p * C + 4 * c4);
     if (pa.gp != nullptr) {
-      const float4 q = pool_adj4<C>(pa, p, c4); gv.x += q.x; gv.y += q.y; gv.z += q.z; gv.w += q.w;
+      const float4 q = pool_adj4<C, HS>(pa, p, c4); gv.x += q.x; gv.y += q.y; gv.z += q.z; gv.w += q.w;
       // the completed gradient goes back in place (g_out == g; each element is read and written by this thread only):
       // the input- and weight-gradient convolutions of this layer form dL/dy from (g, y) while staging (bn_bwd4)
-      if (g_out != nullptr) st4(g_out + p * C + 4 * c4, gv);
+      if (g_out != nullptr) { gv = as_stored4<HS>(gv); stA4<HS>(g_out, p * C + 4 * c4, gv); }   // sums = those of the stored values
     }
     const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
     const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
@@ -269,10 +269,20 @@ int launch_bn_bwd_reduce(const float* g, const float* y, const float* scale, con
   if (gp != nullptr && (H < 2 || W < 2 || H % 2 || W % 2 || npix % ((size_t)H * W))) return SIFSR_ERR_SHAPE;
   if (g_out != nullptr && (g_out != g || gp == nullptr)) return SIFSR_ERR_ARG;   // in place, and only with the pooling adjoint
   const PoolAdj pa{gp, H, W};
+  const bool hs = sifsr_half_storage();
   switch (C) {
-    case 16: hipLaunchKernelGGL((bn_bwd_reduce_kernel<16>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa, g_out); break;
-    case 32: hipLaunchKernelGGL((bn_bwd_reduce_kernel<32>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa, g_out); break;
-    case 64: hipLaunchKernelGGL((bn_bwd_reduce_kernel<64>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa, g_out); break;
+    case 16:
+      if (hs) hipLaunchKernelGGL((bn_bwd_reduce_kernel<16, true>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa, g_out);
+      else hipLaunchKernelGGL((bn_bwd_reduce_kernel<16, false>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa, g_out);
+      break;
+    case 32:
+      if (hs) hipLaunchKernelGGL((bn_bwd_reduce_kernel<32, true>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa, g_out);
+      else hipLaunchKernelGGL((bn_bwd_reduce_kernel<32, false>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa, g_out);
+      break;
+    case 64:
+      if (hs) hipLaunchKernelGGL((bn_bwd_reduce_kernel<64, true>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa, g_out);
+      else hipLaunchKernelGGL((bn_bwd_reduce_kernel<64, false>), dim3(nblk), dim3(256), 0, s, g, y, scale, shift, mean, invstd, npix, partials, pa, g_out);
+      break;
     default: return SIFSR_ERR_SHAPE;
   }
   SIFSR_LAUNCH_CHECK();

@@ -318,6 +318,15 @@ int sifsr_conv3x3_wgrad_bf16(const float* src0, int C0, const float* scale0, con
   return launch_wgrad_reduce(scratch, nblk, cin, cout, wgrad_nbi_chunk(a, cin), dw, S(stream));
 }
 
+// Activation storage of the SINGLE-OPERATOR entry points that are not convolutions (BatchNorm reductions, pooling / upsampling
+// and their adjoints, the thin convs, the fused tail): 1 = their activation tensors are bf16 (what the model's bf16 mode
+// runs), 0 = fp32 (default).  Per calling thread; the model-level calls set it themselves from their compute mode.
+static thread_local HalfStorageScope* t_op_storage = nullptr;
+int sifsr_set_op_storage_bf16(int on) {
+  if (t_op_storage != nullptr) { delete t_op_storage; t_op_storage = nullptr; }
+  if (on) t_op_storage = new HalfStorageScope(true);
+  return SIFSR_OK;
+}
 int sifsr_conv_in_stat_blocks(int B, int H, int W) { return conv_in_fwd_blocks(B, H, W); }
 int sifsr_conv_in_fwd(const float* x, const float* w, float* y, float* stat_partials, int B, int H, int W, void* stream) {
   return launch_conv_in_fwd(x, w, y, stat_partials, B, H, W, S(stream));

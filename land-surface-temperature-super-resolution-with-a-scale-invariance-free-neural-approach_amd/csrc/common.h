@@ -31,6 +31,50 @@ static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v <
 static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// ---- activation storage: fp32, or bf16 in the bf16 compute mode (BASELINE.json config 5) ----
+// Every activation-like tensor INSIDE the model (raw conv outputs, pooled / residual / upsampled tensors, the gradients with
+// respect to them, the image-border scratch of dL/dy) is stored as NHWC bf16 in that mode: half the HBM bytes of every pass.
+// Kernels are templated on HS ("half storage"); pointers stay `float*` in the interfaces (the tensors live in the same
+// workspace regions, using the first half of each), element offsets are in ELEMENTS.  Arithmetic stays fp32: values are
+// widened on load (exact) and rounded to nearest-even on store.
+typedef __attribute__((ext_vector_type(2))) __bf16 sifsr_bf16x2;
+static __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  sifsr_bf16x2 p; p[0] = (__bf16)a; p[1] = (__bf16)b;          // v_cvt_pk_bf16_f32, RNE
+  return __builtin_bit_cast(unsigned, p);
+}
+static __device__ __forceinline__ uint2 pack_bf16x4(float4 v) { return make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+static __device__ __forceinline__ float4 unpack_bf16x4(uint2 u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xFFFF0000u));
+}
+static __device__ __forceinline__ float round_bf16(float a) { return (float)(__bf16)a; }
+static __device__ __forceinline__ float4 round_bf16x4(float4 v) { return unpack_bf16x4(pack_bf16x4(v)); }
+template <bool HS> static __device__ __forceinline__ float4 ldA4(const float* base, size_t e) {   // elements e .. e+3 (e % 4 == 0)
+  if constexpr (HS) return unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + e));
+  else return *reinterpret_cast<const float4*>(base + e);
+}
+template <bool HS> static __device__ __forceinline__ void stA4(float* base, size_t e, float4 v) {
+  if constexpr (HS) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + e) = pack_bf16x4(v);
+  else *reinterpret_cast<float4*>(base + e) = v;
+}
+template <bool HS> static __device__ __forceinline__ float ldA1(const float* base, size_t e) {
+  if constexpr (HS) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(base)[e] << 16);
+  else return base[e];
+}
+// what a consumer of a stored value will read back: the value itself (fp32 storage) or its bf16 rounding
+template <bool HS> static __device__ __forceinline__ float4 as_stored4(float4 v) { if constexpr (HS) return round_bf16x4(v); else return v; }
+
+// Host side: which storage the launch functions of the NON-convolution kernels (BatchNorm reductions, pooling / upsampling and
+// their adjoints, the thin first / last convs, the fused tail) instantiate.  The 3x3 convolution launches carry the compute mode
+// in their argument blocks; everything else asks this thread-local switch, which sifsr_engine_forward / _backward (and the
+// `_bf16` C-ABI entry points of single operators) set for the duration of one call through a HalfStorageScope.
+bool sifsr_half_storage();
+struct HalfStorageScope {
+  bool prev;
+  explicit HalfStorageScope(bool on);
+  ~HalfStorageScope();
+};
+
 // relu(fma(v, scale, shift)) on 4 channels: BatchNorm (folded to scale/shift) + ReLU applied when a
 // consumer loads a raw conv output (model.py:136-137 / :139-140).
 // Written on 2-vectors so that hipcc emits v_pk_fma_f32 / v_pk_max_f32 (two lanes of fp32 per instruction): on gfx950

@@ -58,23 +58,33 @@ static __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigne
 constexpr unsigned OOB = 0xFFFFFF00u;   // per-lane offset beyond any tensor: buffer loads return 0
 
 // ---- bf16 operand mode (BASELINE.json config 5: "bf16 mixed precision, MFMA-bf16 conv tiles") ----
-// Activations and weights stay fp32 in HBM; the producers round them to bf16 (RNE, v_cvt_pk_bf16_f32) while
-// staging, and ONE v_mfma_f32_16x16x32_bf16 (two taps at a time, see the consumer loop) contracts the 16 channels that take four v_mfma_f32_16x16x4_f32 in
-// the fp32 mode -- same lane map (lane (i, kq) holds channels 4kq..4kq+3), fp32 accumulation, fp32 outputs.
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// Activations are STORED as bf16 (round 3; common.h "activation storage"), weights as fp32 master copies with bf16 fragment packs;
+// the producers widen the loaded values, apply the folded BatchNorm + ReLU in fp32, round the result to bf16 (RNE,
+// v_cvt_pk_bf16_f32) into LDS, and ONE v_mfma_f32_16x16x32_bf16 (two taps at a time, see the consumer loop) contracts the 16
+// channels that take four v_mfma_f32_16x16x4_f32 in the fp32 mode -- same lane map (lane (i, kq) holds channels 4kq..4kq+3),
+// fp32 accumulation; the epilogue rounds the outputs to bf16 for the store (statistics are taken of the rounded values: they
+// describe what the consumers will read).
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-static __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-  bf16x2 p; p[0] = (__bf16)a; p[1] = (__bf16)b;
-  return __builtin_bit_cast(unsigned, p);
-}
-static __device__ __forceinline__ uint2 pack_bf16x4(float4 v) { return make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
-static __device__ __forceinline__ float round_bf16(float a) { return (float)(__bf16)a; }
-static __device__ __forceinline__ float4 round_bf16x4(float4 v) { return make_float4(round_bf16(v.x), round_bf16(v.y), round_bf16(v.z), round_bf16(v.w)); }
 static __device__ __forceinline__ uint2 bload2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
   const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
   return make_uint2(v.x, v.y);
+}
+static __device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, uint2 v) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  u32x2 u; u.x = v.x; u.y = v.y;
+  __builtin_amdgcn_raw_buffer_store_b64(u, r, (int)voff, (int)soff, 0);
+}
+// Activation access through a buffer resource: byte offsets are those of the fp32 layout; with half storage (HS) the resource
+// was made with half the size and the offsets are halved (OOB >> 1 = 0x7FFFFF80 stays beyond any bf16 tensor: fp32-sized
+// tensors are limited to 2^32 - 4096 bytes by the launchers).
+template <bool HS> static __device__ __forceinline__ float4 aload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if constexpr (HS) return unpack_bf16x4(bload2(r, voff >> 1, soff >> 1));
+  else return bload4(r, voff, soff);
+}
+template <bool HS> static __device__ __forceinline__ void astore4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 v) {
+  if constexpr (HS) bstore2(r, voff >> 1, soff >> 1, pack_bf16x4(v));
+  else bstore4(r, voff, soff, v);
 }
 
 // 512 threads = 8 waves, specialised by role (one of each per SIMD):
@@ -101,6 +111,8 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
   static_assert(!WINO || (MODE == 0 && NB <= 4), "the Winograd consumer is fp32, up to 64 output channels");
   static_assert(MODE == 0 || MODE == 1, "fp32 or bf16 operands");
   constexpr bool BF16 = MODE != 0;
+  constexpr bool HS = BF16;                                  // bf16 mode: activations are stored as bf16 (common.h)
+  constexpr unsigned ESZ = HS ? 2u : 4u;                     // bytes per stored activation element
   constexpr int CBW = NB >= 4 ? NB / 4 : 1;                  // cout blocks per consumer wave
   constexpr int CST = 4;                                     // ... block nb0 + CST * c
   constexpr int NG = NB == 1 ? 4 : (NB == 2 ? 8 : 16);       // tile rows per consumer wave
@@ -151,10 +163,10 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
     // item's loads from issuing on time.  Producers at 3, consumers at 2: -4 % forward, -6 % input gradient, +0.9 % on the step.
     // (the bf16-operand kernels, HBM-bound throughout, take the same arrangement: +0.8 % on the bf16 step)
     if ((WINO && NB == 1) || MODE == 1) __builtin_amdgcn_s_setprio(3);
-    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.src[0].ptr, npix * a.src[0].C * 4u);
-    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.src[1].ptr ? a.src[1].ptr : a.src[0].ptr, npix * (a.src[1].ptr ? a.src[1].C : a.src[0].C) * 4u);
-    const __amdgpu_buffer_rsrc_t rsy = make_rsrc(DYF ? a.bw_y : a.src[0].ptr, npix * a.src[0].C * 4u);
-    const __amdgpu_buffer_rsrc_t rbd = make_rsrc(DYF && a.bw_border ? a.bw_border : const_cast<float*>(a.src[0].ptr), npix * a.src[0].C * 4u);
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.src[0].ptr, npix * a.src[0].C * ESZ);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.src[1].ptr ? a.src[1].ptr : a.src[0].ptr, npix * (a.src[1].ptr ? a.src[1].C : a.src[0].C) * ESZ);
+    const __amdgpu_buffer_rsrc_t rsy = make_rsrc(DYF ? a.bw_y : a.src[0].ptr, npix * a.src[0].C * ESZ);
+    const __amdgpu_buffer_rsrc_t rbd = make_rsrc(DYF && a.bw_border ? a.bw_border : const_cast<float*>(a.src[0].ptr), npix * a.src[0].C * ESZ);
     // staging map: thread -> (channel quad cg, 6 halo pixels).  Interior tiles: the 6 pixel offsets relative to
     // the halo origin are tile-independent constants; the tile position is a SCALAR offset.
     const int ptid = tid - 256;
@@ -226,8 +238,8 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
 #pragma unroll
       for (int it = 0; it < 6; ++it) {
         const unsigned voff = (ZERO_PAD && pixv[it] < 0) ? OOB : (((unsigned)pixv[it] << lgc) + (unsigned)cg * 16u);
-        stg[it] = bload4(r, voff, soff);
-        if (DYF) styA[it] = bload4(rsy, voff, soff);
+        stg[it] = aload4<HS>(r, voff, soff);
+        if (DYF) styA[it] = aload4<HS>(rsy, voff, soff);
       }
       const float* scp = first ? a.src[0].scale : a.src[1].scale;
       const float* shp = first ? a.src[0].shift : a.src[1].shift;
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
             const bool core = spy[it] >= 1 && spy[it] <= 16 && spx[it] >= 1 && spx[it] <= 16;
             const bool edge = gy == 0 || gy == H - 1 || gx == 0 || gx == W - 1;
             if (a.bw_border != nullptr && inside && core && edge && (it < 5 || pslot < PW * PW - 320))
-              bstore4(rbd, (unsigned)((wb * H + gy) * W + gx) * (unsigned)a.src[0].C * 4u + (unsigned)(16 * qA + 4 * cg) * 4u, 0u, v);
+              astore4<HS>(rbd, (unsigned)((wb * H + gy) * W + gx) * (unsigned)a.src[0].C * 4u + (unsigned)(16 * qA + 4 * cg) * 4u, 0u, v);
           }
         } else if (!praw) v = bn_relu4(v, psc, psh);
         if (it < 5 || pslot < PW * PW - 320) {
@@ -304,11 +316,11 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
   const int nb0 = NB == 1 ? 0 : (NB == 2 ? (wave & 1) : wave);
   const int g0 = NB == 1 ? wave * 4 : (NB == 2 ? (wave >> 1) * 8 : 0);
   const int kq = lane >> 4, px = lane & 15;
-  const __amdgpu_buffer_rsrc_t rd0 = make_rsrc(a.dst[0].ptr, npix * a.dst[0].C * 4u);
-  const __amdgpu_buffer_rsrc_t rd1 = make_rsrc(a.dst[1].ptr, npix * a.dst[1].C * 4u);
-  const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.addend ? a.addend : a.dst[0].ptr, npix * (a.addend ? a.addC : a.dst[0].C) * 4u);
+  const __amdgpu_buffer_rsrc_t rd0 = make_rsrc(a.dst[0].ptr, npix * a.dst[0].C * ESZ);
+  const __amdgpu_buffer_rsrc_t rd1 = make_rsrc(a.dst[1].ptr, npix * a.dst[1].C * ESZ);
+  const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.addend ? a.addend : a.dst[0].ptr, npix * (a.addend ? a.addC : a.dst[0].C) * ESZ);
   const bool bn_stats = NB == 1 && ZERO_PAD && a.bn_y != nullptr;     // BatchNorm-backward sums of the previous layer
-  const __amdgpu_buffer_rsrc_t rby = make_rsrc(bn_stats ? a.bn_y : a.dst[0].ptr, npix * 64u);
+  const __amdgpu_buffer_rsrc_t rby = make_rsrc(bn_stats ? a.bn_y : a.dst[0].ptr, npix * 16u * ESZ);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpack, (unsigned)(NB * 16) * (unsigned)(NQ * 16) * (BF16 ? 18u : 36u));
 
   float4 wf[BF16 ? 1 : CBW][BF16 ? 1 : 9];
@@ -560,7 +572,7 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
       bsc = ld4(a.bn_scale + 4 * kq); bsh = ld4(a.bn_shift + 4 * kq);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        yq[g] = bload4(rby, (colok_ && g < rows_ok_) ? (unsigned)px * 64u + (unsigned)kq * 16u : OOB, (tp_ + (unsigned)(g * W)) * 64u);
+        yq[g] = aload4<HS>(rby, (colok_ && g < rows_ok_) ? (unsigned)px * 64u + (unsigned)kq * 16u : OOB, (tp_ + (unsigned)(g * W)) * 64u);
     }
     const float4* L = lds[buf];
     // The weights of the NEXT item (channel block q+1, or block 0 of the next tile; NQ == 1: the same ones again) are
@@ -681,10 +693,14 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
         acc[c][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (g >= rows_ok) continue;
         if (a.addend != nullptr) {
-          const float4 ad = bload4(rad, va, rowpix * (unsigned)a.addC * 4u);
+          const float4 ad = aload4<HS>(rad, va, rowpix * (unsigned)a.addC * 4u);
           v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
         }
-        bstore4(rd, vo, rowpix * (unsigned)dC * 4u, make_float4(v[0], v[1], v[2], v[3]));
+        if (HS) {   // the statistics below are those of the STORED (bf16-rounded) values
+          const float4 vr = round_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
+          v = (f32x4){vr.x, vr.y, vr.z, vr.w};
+        }
+        astore4<HS>(rd, vo, rowpix * (unsigned)dC * 4u, make_float4(v[0], v[1], v[2], v[3]));
         if (NB == 1 && bn_stats) {    // dz = g * [y*scale + shift > 0]; sum dz, sum dz*y (masked lanes read y = 0, v ignored)
           const float yy[4] = {yq[g].x, yq[g].y, yq[g].z, yq[g].w};
           const float scv[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, shv[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
@@ -879,10 +895,13 @@ __global__ __launch_bounds__(256, 8) void dgrad_border_kernel(const float* __res
   // read 0) and weights before the first MFMA.
   const size_t pix_o = valid ? (size_t)(b * H + qy) * W + qx : 0;
   const int ci_o = 16 * nb + 4 * kq;
-  float* const dst = ci_o < split_ch ? g0 + pix_o * C0 + ci_o : g1 + pix_o * C1 + (ci_o - split_ch);
-  const float4 g_old = valid ? ld4(dst) : z4;
+  // bf16 != 0: the compute mode whose activations are STORED as bf16 (common.h): dy, g0 / g1 and bn_y are bf16 tensors
+  float* const dbase = ci_o < split_ch ? g0 : g1;
+  const size_t de = ci_o < split_ch ? pix_o * C0 + ci_o : pix_o * C1 + (ci_o - split_ch);   // element index
+  const float4 g_old = valid ? (bf16 ? ldA4<true>(dbase, de) : ldA4<false>(dbase, de)) : z4;
 
-  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (unsigned)B * (unsigned)H * (unsigned)W * (unsigned)Cout * 4u);
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (unsigned)B * (unsigned)H * (unsigned)W * (unsigned)Cout * (bf16 ? 2u : 4u));
+  auto dyload = [&](unsigned voff, unsigned soff) { return bf16 ? aload4<true>(rdy, voff, soff) : aload4<false>(rdy, voff, soff); };
   auto poff = [&](int y, int x, bool ok) {
     return ok ? (unsigned)((b * H + y) * W + x) * (unsigned)Cout * 4u + (unsigned)kq * 16u : OOB;
   };
@@ -922,7 +941,7 @@ __global__ __launch_bounds__(256, 8) void dgrad_border_kernel(const float* __res
     float4 rv[3], wv[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      rv[i] = bload4(rdy, ro[i], (unsigned)q * 64u);
+      rv[i] = dyload(ro[i], (unsigned)q * 64u);
       wv[i] = ld4(wbase + ((size_t)q * 9 + wt[i]) * 256);
     }
 #pragma unroll
@@ -932,8 +951,8 @@ __global__ __launch_bounds__(256, 8) void dgrad_border_kernel(const float* __res
       for (int sd = 0; sd < 2; ++sd) {                       // left corner, then right corner
         const int xc = sd == 0 ? 0 : W - 1;
         const bool on = (sd == 0 ? cl : cr) && valid && qx == xc;
-        rv[0] = bload4(rdy, poff(qy, xc, on), (unsigned)q * 64u);
-        rv[1] = bload4(rdy, poff(yin, xc, on), (unsigned)q * 64u);
+        rv[0] = dyload(poff(qy, xc, on), (unsigned)q * 64u);
+        rv[1] = dyload(poff(yin, xc, on), (unsigned)q * 64u);
         wv[0] = ld4(wbase + ((size_t)q * 9 + (8 - (1 * 3 + 2 * sd))) * 256);
         wv[1] = ld4(wbase + ((size_t)q * 9 + (8 - ((ty_tb + 1) * 3 + 2 * sd))) * 256);
         if (bf16) { rv[0] = round_bf16x4(rv[0]); rv[1] = round_bf16x4(rv[1]); }
@@ -946,14 +965,15 @@ __global__ __launch_bounds__(256, 8) void dgrad_border_kernel(const float* __res
     // D rows = ci 4*kq + r, col = pixel  ->  one float4 read-modify-write per lane (read issued at the top)
     float4 v = g_old;
     v.x += acc[0]; v.y += acc[1]; v.z += acc[2]; v.w += acc[3];
-    st4(dst, v);
+    if (bf16) stA4<true>(dbase, de, v); else stA4<false>(dbase, de, v);
   }
   if (bn_partials != nullptr) {
     // the BatchNorm-backward sums are linear in g: this wave adds (delta*mask, delta*mask*y) of its 16 border pixels
     // for its 16 channels (Cin == 16 here, nb == 0); rows of bn_partials = global wave index
     float d1[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f};
     if (valid) {   // loaded here, not at the top: 12 live registers through the MFMA loop would break the 64-register budget
-      const float4 yv = ld4(bn_y + pix_o * 16 + 4 * kq), bsc = ld4(bn_scale + 4 * kq), bsh = ld4(bn_shift + 4 * kq);
+      const float4 yv = bf16 ? ldA4<true>(bn_y, pix_o * 16 + 4 * kq) : ldA4<false>(bn_y, pix_o * 16 + 4 * kq);
+      const float4 bsc = ld4(bn_scale + 4 * kq), bsh = ld4(bn_shift + 4 * kq);
       const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, scv[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, shv[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

@@ -23,6 +23,18 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const float* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
 }
+// activation loads: offsets are those of the fp32 layout; HS (bf16 storage, the bf16 compute mode -- common.h) halves them
+template <bool HS> static __device__ __forceinline__ float4 wg_aload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if constexpr (HS) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2w;
+    const u32x2w v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(voff >> 1), (int)(soff >> 1), 0);
+    return unpack_bf16x4(make_uint2(v.x, v.y));
+  } else {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4w;
+    const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  }
+}
 static __device__ __forceinline__ float4 wg_bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
@@ -73,9 +85,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
   const ConvSrc& src = first ? a.src[0] : a.src[1];
   const int ch0 = src.coff + 16 * (first ? q0 : q0 - a.src[0].nq);
   const int lgc = 31 - __builtin_clz((unsigned)src.C) + 2;                 // log2(C * 4 bytes)
-  const __amdgpu_buffer_rsrc_t rin = wg_rsrc(src.ptr, npix * (unsigned)src.C * 4u);
-  const __amdgpu_buffer_rsrc_t rdy = wg_rsrc(a.dy, npix * (unsigned)Cout * 4u);
-  const __amdgpu_buffer_rsrc_t rdyy = wg_rsrc(DYF ? a.dy_y : a.dy, npix * (unsigned)Cout * 4u);
+  constexpr bool HS = BF16;                                               // bf16 mode: activations stored as bf16
+  constexpr unsigned ESZ = HS ? 2u : 4u;
+  const __amdgpu_buffer_rsrc_t rin = wg_rsrc(src.ptr, npix * (unsigned)src.C * ESZ);
+  const __amdgpu_buffer_rsrc_t rdy = wg_rsrc(a.dy, npix * (unsigned)Cout * ESZ);
+  const __amdgpu_buffer_rsrc_t rdyy = wg_rsrc(DYF ? a.dy_y : a.dy, npix * (unsigned)Cout * ESZ);
 
   // ---- per-thread staging constants (tile independent) ----
   const int c4o = tid % QO, po0 = tid / QO;      // dy: pixel po0 + i*PPO, channels 4*c4o..
@@ -122,8 +136,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
     if (x0 + 16 <= W && y0 + WT_ROWS <= H) {
 #pragma unroll
       for (int i = 0; i < NIO; ++i) {
-        pdy[i] = wg_bload4(rdy, vo_dy[i], base * (unsigned)(Cout * 4));
-        if (DYF) pyy[i] = wg_bload4(rdyy, vo_dy[i], base * (unsigned)(Cout * 4));
+        pdy[i] = wg_aload4<HS>(rdy, vo_dy[i], base * (unsigned)(Cout * 4));
+        if (DYF) pyy[i] = wg_aload4<HS>(rdyy, vo_dy[i], base * (unsigned)(Cout * 4));
       }
     } else {
       // partial tile: dy of the pixels outside the image must read as 0 (they contribute nothing to dW):
@@ -132,8 +146,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
       for (int i = 0; i < NIO; ++i) {
         const int p = po0 + i * PPO;
         const bool in = y0 + (p >> 4) < H && x0 + (p & 15) < W;
-        pdy[i] = wg_bload4(rdy, in ? vo_dy[i] : 0xFFFFFF00u, base * (unsigned)(Cout * 4));
-        if (DYF) pyy[i] = wg_bload4(rdyy, in ? vo_dy[i] : 0xFFFFFF00u, base * (unsigned)(Cout * 4));
+        pdy[i] = wg_aload4<HS>(rdy, in ? vo_dy[i] : 0xFFFFFF00u, base * (unsigned)(Cout * 4));
+        if (DYF) pyy[i] = wg_aload4<HS>(rdyy, in ? vo_dy[i] : 0xFFFFFF00u, base * (unsigned)(Cout * 4));
       }
     }
     const bool interior = txi > 0 && tyi > 0 && txi + 1 < tiles_x && tyi + 1 < tiles_y;
@@ -141,12 +155,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a, c
     if (interior) {
       const unsigned soff = ((base - (unsigned)W - 1u) << lgc);
 #pragma unroll
-      for (int i = 0; i < NII; ++i) pin[i] = wg_bload4(rin, ((unsigned)(ipy[i] * W + ipx[i]) << lgc) + chb, soff);
+      for (int i = 0; i < NII; ++i) pin[i] = wg_aload4<HS>(rin, ((unsigned)(ipy[i] * W + ipx[i]) << lgc) + chb, soff);
     } else {
 #pragma unroll
       for (int i = 0; i < NII; ++i) {
         const int gy = clampi(y0 - 1 + ipy[i], 0, H - 1), gx = clampi(x0 - 1 + ipx[i], 0, W - 1);
-        pin[i] = wg_bload4(rin, ((unsigned)((b * H + gy) * W + gx) << lgc) + chb, 0u);
+        pin[i] = wg_aload4<HS>(rin, ((unsigned)((b * H + gy) * W + gx) << lgc) + chb, 0u);
       }
     }
   };

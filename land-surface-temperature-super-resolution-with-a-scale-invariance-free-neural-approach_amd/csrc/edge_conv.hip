@@ -15,6 +15,7 @@ namespace {
 // channels of one pixel per lane) is exactly one 16-byte NHWC store, and the BatchNorm sums fall out of the same
 // registers.  (The scalar version: 288 FMAs per pixel, statistics transposed through LDS, 102-110 us against a 55 us
 // write floor.)
+template <bool HS>   // HS: y stored as bf16 (the bf16 compute mode, common.h); the statistics are those of the stored values
 __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           float* __restrict__ y, float* __restrict__ partials,
                                                           int B, int H, int W) {
@@ -61,9 +62,11 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
       for (int j = 0; j < 5; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], T[off[j] + row * 18], acc, 0, 0, 0);
       // lane: output channels 4*kq .. 4*kq+3 of pixel (row, i); partial tiles when H or W is not a multiple of 16
       if (y0 + row < H && x0 + i < W) {
-        st4(y + ((size_t)(b * H + y0 + row) * W + x0 + i) * 16 + 4 * kq, make_float4(acc[0], acc[1], acc[2], acc[3]));
+        const float4 o = as_stored4<HS>(make_float4(acc[0], acc[1], acc[2], acc[3]));
+        stA4<HS>(y, ((size_t)(b * H + y0 + row) * W + x0 + i) * 16 + 4 * kq, o);
+        const float ov[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { s1[q] += acc[q]; s2[q] = fmaf(acc[q], acc[q], s2[q]); }
+        for (int q = 0; q < 4; ++q) { s1[q] += ov[q]; s2[q] = fmaf(ov[q], ov[q], s2[q]); }
       }
     }
   }
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
 // FUSED: dy is not read but computed while staging, dy = scale*g*[z>0] + k1*y + k0 (the BatchNorm+ReLU backward
 // of inbloc.bloc.1/2; `dy` then holds g) -- the first layer has no input gradient, so this wgrad is dy's only
 // consumer and dy never goes to HBM.
-template <bool FUSED>
+template <bool FUSED, bool HS>
 __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ yraw,
                                                             const float* __restrict__ scale,
@@ -137,9 +140,9 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restr
         continue;
       }
       const size_t off = ((size_t)(b * H + y0 + (p >> 4)) * W + x0 + (p & 15)) * 16 + 4 * c4;
-      float4 v = ld4(dy + off);
+      float4 v = ldA4<HS>(dy, off);
       if (FUSED) {
-        const float4 yv = ld4(yraw + off);
+        const float4 yv = ldA4<HS>(yraw, off);
         v.x = (float)fma(sd[0], (double)(fmaf(yv.x, sc4.x, sh4.x) > 0.f ? v.x : 0.f), fma(k1[0], (double)yv.x, k0[0]));
         v.y = (float)fma(sd[1], (double)(fmaf(yv.y, sc4.y, sh4.y) > 0.f ? v.y : 0.f), fma(k1[1], (double)yv.y, k0[1]));
         v.z = (float)fma(sd[2], (double)(fmaf(yv.z, sc4.z, sh4.z) > 0.f ? v.z : 0.f), fma(k1[2], (double)yv.z, k0[2]));
@@ -183,6 +186,7 @@ constexpr int OCS = 20;   // LDS pixel stride (floats): 5 slots of 16 B -> confl
 //      applied in registers), B operand = 4 weights per lane held for the whole kernel; no LDS staging of the input.
 //   2. out[p] = bias + sum_t P[p + t][t]: nine LDS reads per output pixel.
 // The scalar version (144 FMAs and 36 ds_read_b128 per pixel) ran at 114-127 us against a 50 us HBM floor.
+template <bool HS>
 __global__ __launch_bounds__(256) void conv_out_fwd_kernel(const float* __restrict__ y, const float* scale,
                                                            const float* shift, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out,
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_out_fwd_kernel(const float* __restri
     if (p > 323) p = 323;                        // the last group is partial; group 21+ does not exist (clamped, unused)
     const int r = p / 18, c = p - r * 18;
     const int gy = clampi(y0 - 1 + r, 0, H - 1), gx = clampi(x0 - 1 + c, 0, W - 1);   // replicate padding
-    v[n] = ld4(y + ((size_t)(b * H + gy) * W + gx) * 16 + 4 * kq);
+    v[n] = ldA4<HS>(y, ((size_t)(b * H + gy) * W + gx) * 16 + 4 * kq);
   }
 #pragma unroll
   for (int n = 0; n < NPW; ++n) {
@@ -353,7 +357,8 @@ int conv_in_fwd_blocks(int B, int H, int W) {   // workgroups launched == statis
 
 int launch_conv_in_fwd(const float* x, const float* w, float* y, float* partials, int B, int H, int W, hipStream_t s) {
   if (H < 1 || W < 1 || B < 1) return SIFSR_ERR_SHAPE;
-  hipLaunchKernelGGL(conv_in_fwd_kernel, dim3(conv_in_fwd_blocks(B, H, W)), dim3(256), 0, s, x, w, y, partials, B, H, W);
+  if (sifsr_half_storage()) hipLaunchKernelGGL(conv_in_fwd_kernel<true>, dim3(conv_in_fwd_blocks(B, H, W)), dim3(256), 0, s, x, w, y, partials, B, H, W);
+  else hipLaunchKernelGGL(conv_in_fwd_kernel<false>, dim3(conv_in_fwd_blocks(B, H, W)), dim3(256), 0, s, x, w, y, partials, B, H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
@@ -361,8 +366,8 @@ int launch_conv_in_fwd(const float* x, const float* w, float* y, float* partials
 int launch_conv_in_wgrad(const float* x, const float* dy, float* partials, int nblk, float* dw, int B, int H, int W,
                          hipStream_t s) {
   if (H < 1 || W < 1) return SIFSR_ERR_SHAPE;
-  hipLaunchKernelGGL((conv_in_wgrad_kernel<false>), dim3(nblk), dim3(256), 0, s, x, dy, nullptr, nullptr, nullptr, nullptr,
-                     partials, B, H, W);
+  if (sifsr_half_storage()) hipLaunchKernelGGL((conv_in_wgrad_kernel<false, true>), dim3(nblk), dim3(256), 0, s, x, dy, nullptr, nullptr, nullptr, nullptr, partials, B, H, W);
+  else hipLaunchKernelGGL((conv_in_wgrad_kernel<false, false>), dim3(nblk), dim3(256), 0, s, x, dy, nullptr, nullptr, nullptr, nullptr, partials, B, H, W);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(72), dim3(256), 0, s, partials, nblk, 288, dw);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
@@ -372,7 +377,8 @@ int launch_conv_in_wgrad_fused(const float* x, const float* g, const float* y, c
                                const double* coef, float* partials, int nblk, float* dw, int B, int H, int W,
                                hipStream_t s) {
   if (H < 1 || W < 1) return SIFSR_ERR_SHAPE;
-  hipLaunchKernelGGL((conv_in_wgrad_kernel<true>), dim3(nblk), dim3(256), 0, s, x, g, y, scale, shift, coef, partials, B, H, W);
+  if (sifsr_half_storage()) hipLaunchKernelGGL((conv_in_wgrad_kernel<true, true>), dim3(nblk), dim3(256), 0, s, x, g, y, scale, shift, coef, partials, B, H, W);
+  else hipLaunchKernelGGL((conv_in_wgrad_kernel<true, false>), dim3(nblk), dim3(256), 0, s, x, g, y, scale, shift, coef, partials, B, H, W);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(72), dim3(256), 0, s, partials, nblk, 288, dw);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
@@ -381,7 +387,8 @@ int launch_conv_in_wgrad_fused(const float* x, const float* g, const float* y, c
 int launch_conv_out_fwd(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
                         float* out, int B, int H, int W, hipStream_t s) {
   if (H < 1 || W < 1) return SIFSR_ERR_SHAPE;
-  hipLaunchKernelGGL(conv_out_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16, B), dim3(256), 0, s, y, scale, shift, w, bias, out, H, W);
+  if (sifsr_half_storage()) hipLaunchKernelGGL(conv_out_fwd_kernel<true>, dim3((W + 15) / 16, (H + 15) / 16, B), dim3(256), 0, s, y, scale, shift, w, bias, out, H, W);
+  else hipLaunchKernelGGL(conv_out_fwd_kernel<false>, dim3((W + 15) / 16, (H + 15) / 16, B), dim3(256), 0, s, y, scale, shift, w, bias, out, H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

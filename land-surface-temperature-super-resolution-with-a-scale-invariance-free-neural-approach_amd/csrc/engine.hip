@@ -17,6 +17,14 @@
 #include <vector>
 
 // ---------------------------------------------------------------------------------------------
+// activation storage of the current call (common.h)
+// ---------------------------------------------------------------------------------------------
+static thread_local bool t_half_storage = false;
+bool sifsr_half_storage() { return t_half_storage; }
+HalfStorageScope::HalfStorageScope(bool on) : prev(t_half_storage) { t_half_storage = on; }
+HalfStorageScope::~HalfStorageScope() { t_half_storage = prev; }
+
+// ---------------------------------------------------------------------------------------------
 // network table
 // ---------------------------------------------------------------------------------------------
 static NetTable build_net() {
@@ -510,6 +518,7 @@ int sifsr_engine_forward(const float* x, float* sr, const float* params, float* 
   Ctx c{sifsr_net(), WsLayout(), ws, params, B, H, W, s};
   if (bf16 < 0 || bf16 > 1) return SIFSR_ERR_ARG;
   c.bf16 = bf16;
+  const HalfStorageScope storage(bf16 == 1);   // bf16 mode: every activation-like tensor of the workspace is stored as bf16
   SIFSR_TRY(sifsr_layout(B, H, W, training, &c.lay));
   // a forward touches [0, fwd_end) only; the backward regions behind it are checked by sifsr_engine_backward.  So a
   // training-mode forward that will never be followed by a backward (torch.no_grad(): BatchNorm recalibration,
@@ -578,6 +587,7 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   Ctx c{sifsr_net(), WsLayout(), ws, params, B, H, W, s};
   if (bf16 < 0 || bf16 > 1) return SIFSR_ERR_ARG;
   c.bf16 = bf16;
+  const HalfStorageScope storage(bf16 == 1);
   SIFSR_TRY(sifsr_layout(B, H, W, 1, &c.lay));
   if (ws_floats < c.lay.total) return SIFSR_ERR_WORKSPACE;
   const NetTable& nt = c.nt;

@@ -65,6 +65,7 @@ __device__ __forceinline__ float outlay_S1(const float* dt, int ly, int lx, int 
 // the D fragment of the second (4 channels x 1 pixel per lane) is consumed in registers by the BatchNorm
 // reduction: dz = g*[z>0]; sum dz and sum dz*y per channel (fp32 per lane over the workgroup's tiles -- a few
 // hundred terms -- float64 across lanes, waves and workgroups).
+template <bool HS>   // HS: y stored as bf16 (the bf16 compute mode, common.h)
 __global__ __launch_bounds__(256, 2) void tail_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift,
                                                                  const float* __restrict__ mean,
@@ -109,14 +110,14 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_reduce_kernel(const float* __
     const int x0 = tx * 16, y0 = ty * 16;
     const bool border = tx == 0 || ty == 0 || tx == tiles_x - 1 || ty == tiles_y - 1;
     if (!border) {
-      const float* yb = y + ((size_t)(b * H + y0 - 1) * W + x0 - 1) * 16;
+      const size_t yb = ((size_t)(b * H + y0 - 1) * W + x0 - 1) * 16;
       const float* db = dsr + (size_t)(b * H + y0 - 1) * W + x0 - 1;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int e = tid + 256 * i;
         if (e < 324 * 4) {
           const int hy = (e >> 2) / 18;
-          py[i] = ld4(yb + hy * (W - 18) * 16 + e * 4);   // ((hy*W + hx)*16 + 4*q4), e = (hy*18 + hx)*4 + q4
+          py[i] = ldA4<HS>(y, yb + (size_t)(hy * (W - 18) * 16 + e * 4));   // ((hy*W + hx)*16 + 4*q4), e = (hy*18 + hx)*4 + q4
         }
       }
 #pragma unroll
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_reduce_kernel(const float* __
         if (e < 324 * 4) {
           const int p = e >> 2, hy = p / 18, hx = p - hy * 18;
           const int gy = clampi(y0 - 1 + hy, 0, H - 1), gx = clampi(x0 - 1 + hx, 0, W - 1);
-          py[i] = ld4(y + ((size_t)(b * H + gy) * W + gx) * 16 + 4 * (e & 3));
+          py[i] = ldA4<HS>(y, ((size_t)(b * H + gy) * W + gx) * 16 + 4 * (e & 3));
         }
       }
 #pragma unroll
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_reduce_kernel(const float* __
   }
 }
 
+template <bool HS>   // HS: y read and dy written as bf16
 __global__ __launch_bounds__(256) void tail_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                              const float* __restrict__ shift,
                                                              const double* __restrict__ coef,
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256) void tail_bwd_apply_kernel(const float* __rest
     const int p = pass * 64 + pl, ly = p >> 4, lx = p & 15;
     if (y0 + ly >= H || x0 + lx >= W) continue;
     const size_t off = ((size_t)(b * H + y0 + ly) * W + x0 + lx) * 16 + 4 * c4;
-    const float4 yv = ld4(y + off);
+    const float4 yv = ldA4<HS>(y, off);
     float S[9];
     outlay_gather(dt, ly, lx, y0 + ly == 0, y0 + ly == H - 1, x0 + lx == 0, x0 + lx == W - 1, S);
     const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void tail_bwd_apply_kernel(const float* __rest
       const float dz = fmaf(yy[j], scv[j], shv[j]) > 0.f ? g : 0.f;
       o[j] = (float)fma(sd[j], (double)dz, fma(k1[j], (double)yy[j], k0[j]));
     }
-    st4(dy + off, make_float4(o[0], o[1], o[2], o[3]));
+    stA4<HS>(dy, off, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
@@ -287,8 +289,8 @@ int launch_tail_bwd_reduce(const float* y, const float* scale, const float* shif
                            const float* dsr, const float* w, float* wpart, float* bnpart, int nblk, int B, int H, int W,
                            hipStream_t s) {
   if (H < 3 || W < 3 || nblk < 1) return SIFSR_ERR_SHAPE;
-  hipLaunchKernelGGL(tail_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, s, y, scale, shift, mean, invstd, dsr, w, wpart,
-                     bnpart, B, H, W);
+  if (sifsr_half_storage()) hipLaunchKernelGGL(tail_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, s, y, scale, shift, mean, invstd, dsr, w, wpart, bnpart, B, H, W);
+  else hipLaunchKernelGGL(tail_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, y, scale, shift, mean, invstd, dsr, w, wpart, bnpart, B, H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
@@ -296,7 +298,8 @@ int launch_tail_bwd_reduce(const float* y, const float* scale, const float* shif
 int launch_tail_bwd_apply(const float* y, const float* scale, const float* shift, const double* coef, const float* dsr,
                           const float* w, float* dy, int B, int H, int W, hipStream_t s) {
   if (H < 3 || W < 3) return SIFSR_ERR_SHAPE;
-  hipLaunchKernelGGL(tail_bwd_apply_kernel, dim3((W + 15) / 16, (H + 15) / 16, B), dim3(256), 0, s, y, scale, shift, coef, dsr, w, dy, H, W);
+  if (sifsr_half_storage()) hipLaunchKernelGGL(tail_bwd_apply_kernel<true>, dim3((W + 15) / 16, (H + 15) / 16, B), dim3(256), 0, s, y, scale, shift, coef, dsr, w, dy, H, W);
+  else hipLaunchKernelGGL(tail_bwd_apply_kernel<false>, dim3((W + 15) / 16, (H + 15) / 16, B), dim3(256), 0, s, y, scale, shift, coef, dsr, w, dy, H, W);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

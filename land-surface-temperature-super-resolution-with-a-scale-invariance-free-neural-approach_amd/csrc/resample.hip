@@ -1,4 +1,5 @@
-// Resampling glue of the U-Net (all NHWC fp32, one thread per (pixel, channel quad)):
+// Resampling glue of the U-Net (all NHWC, fp32 or -- HS, the bf16 compute mode -- bf16 storage with fp32 arithmetic; one thread per
+// (pixel, channel quad)):
 //   * AvgPool2d(2,2) of relu(bn(y))                        -- DownBlock_pool, model.py:504
 //   * residual sum  x + relu(bn(DoubleConv(x)))            -- ResidualConnection, model.py:311-312
 //   * Upsample(x2, bilinear, align_corners=True) of relu(bn(y)) -- UpBlock, model.py:207
@@ -12,6 +13,7 @@ __device__ __forceinline__ float4 maybe_bnrelu(float4 v, const float* scale, con
   return scale != nullptr ? bn_relu4(v, ld4(scale + c), ld4(shift + c)) : v;
 }
 
+template <bool HS>
 __global__ void bnrelu_pool2_kernel(const float* __restrict__ y, const float* scale, const float* shift,
                                     float* __restrict__ out, int B, int H, int W, int C) {
   const int Q = C / 4, Ho = H / 2, Wo = W / 2;
@@ -20,26 +22,27 @@ __global__ void bnrelu_pool2_kernel(const float* __restrict__ y, const float* sc
     const int c = (int)(e % Q) * 4;
     const size_t p = e / Q;
     const int ox = p % Wo, oy = (p / Wo) % Ho, b = p / ((size_t)Wo * Ho);
-    const float* s = y + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
-    const float4 v00 = maybe_bnrelu(ld4(s), scale, shift, c), v01 = maybe_bnrelu(ld4(s + C), scale, shift, c);
-    const float4 v10 = maybe_bnrelu(ld4(s + (size_t)W * C), scale, shift, c);
-    const float4 v11 = maybe_bnrelu(ld4(s + (size_t)W * C + C), scale, shift, c);
+    const size_t s = (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+    const float4 v00 = maybe_bnrelu(ldA4<HS>(y, s), scale, shift, c), v01 = maybe_bnrelu(ldA4<HS>(y, s + C), scale, shift, c);
+    const float4 v10 = maybe_bnrelu(ldA4<HS>(y, s + (size_t)W * C), scale, shift, c);
+    const float4 v11 = maybe_bnrelu(ldA4<HS>(y, s + (size_t)W * C + C), scale, shift, c);
     float4 o;
     o.x = (v00.x + v01.x + v10.x + v11.x) * 0.25f;
     o.y = (v00.y + v01.y + v10.y + v11.y) * 0.25f;
     o.z = (v00.z + v01.z + v10.z + v11.z) * 0.25f;
     o.w = (v00.w + v01.w + v10.w + v11.w) * 0.25f;
-    st4(out + p * C + c, o);
+    stA4<HS>(out, p * C + c, o);
   }
 }
 
+template <bool HS>
 __global__ void bnrelu_add_kernel(const float* __restrict__ p, const float* __restrict__ y, const float* scale,
                                   const float* shift, float* __restrict__ out, int C, size_t nquads) {
   const int Q = C / 4;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nquads; e += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(e % Q) * 4;
-    const float4 a = ld4(p + e * 4), v = maybe_bnrelu(ld4(y + e * 4), scale, shift, c);
-    st4(out + e * 4, make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w));
+    const float4 a = ldA4<HS>(p, e * 4), v = maybe_bnrelu(ldA4<HS>(y, e * 4), scale, shift, c);
+    stA4<HS>(out, e * 4, make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w));
   }
 }
 
@@ -54,6 +57,7 @@ __device__ __forceinline__ void up_coord(int o, int in, int out, int& i0, int& i
   l0 = 1.f - l1;
 }
 
+template <bool HS>
 __global__ void bnrelu_up2x_kernel(const float* __restrict__ y, const float* scale, const float* shift,
                                    float* __restrict__ out, int B, int Hin, int Win, int C) {
   const int Q = C / 4, Ho = 2 * Hin, Wo = 2 * Win;
@@ -65,21 +69,22 @@ __global__ void bnrelu_up2x_kernel(const float* __restrict__ y, const float* sca
     int y0, y1, x0, x1; float hy0, hy1, hx0, hx1;
     up_coord(oy, Hin, Ho, y0, y1, hy0, hy1);
     up_coord(ox, Win, Wo, x0, x1, hx0, hx1);
-    const float* base = y + (size_t)b * Hin * Win * C + c;
-    const float4 v00 = maybe_bnrelu(ld4(base + ((size_t)y0 * Win + x0) * C), scale, shift, c);
-    const float4 v01 = maybe_bnrelu(ld4(base + ((size_t)y0 * Win + x1) * C), scale, shift, c);
-    const float4 v10 = maybe_bnrelu(ld4(base + ((size_t)y1 * Win + x0) * C), scale, shift, c);
-    const float4 v11 = maybe_bnrelu(ld4(base + ((size_t)y1 * Win + x1) * C), scale, shift, c);
+    const size_t base = (size_t)b * Hin * Win * C + c;
+    const float4 v00 = maybe_bnrelu(ldA4<HS>(y, base + ((size_t)y0 * Win + x0) * C), scale, shift, c);
+    const float4 v01 = maybe_bnrelu(ldA4<HS>(y, base + ((size_t)y0 * Win + x1) * C), scale, shift, c);
+    const float4 v10 = maybe_bnrelu(ldA4<HS>(y, base + ((size_t)y1 * Win + x0) * C), scale, shift, c);
+    const float4 v11 = maybe_bnrelu(ldA4<HS>(y, base + ((size_t)y1 * Win + x1) * C), scale, shift, c);
     float4 o;
     o.x = hy0 * (hx0 * v00.x + hx1 * v01.x) + hy1 * (hx0 * v10.x + hx1 * v11.x);
     o.y = hy0 * (hx0 * v00.y + hx1 * v01.y) + hy1 * (hx0 * v10.y + hx1 * v11.y);
     o.z = hy0 * (hx0 * v00.z + hx1 * v01.z) + hy1 * (hx0 * v10.z + hx1 * v11.z);
     o.w = hy0 * (hx0 * v00.w + hx1 * v01.w) + hy1 * (hx0 * v10.w + hx1 * v11.w);
-    st4(out + p * C + c, o);
+    stA4<HS>(out, p * C + c, o);
   }
 }
 
 // adjoint of AvgPool2d(2,2): g[y][x] (+)= 0.25 * gp[y/2][x/2]
+template <bool HS>
 __global__ void pool2_bwd_kernel(const float* __restrict__ gp, float* __restrict__ g, int B, int H, int W, int C,
                                  int accumulate) {
   const int Q = C / 4, Ho = H / 2, Wo = W / 2;
@@ -88,19 +93,20 @@ __global__ void pool2_bwd_kernel(const float* __restrict__ gp, float* __restrict
     const int c = (int)(e % Q) * 4;
     const size_t p = e / Q;
     const int x = p % W, yy = (p / W) % H, b = p / ((size_t)W * H);
-    const float4 v = ld4(gp + (((size_t)b * Ho + yy / 2) * Wo + x / 2) * C + c);
+    const float4 v = ldA4<HS>(gp, (((size_t)b * Ho + yy / 2) * Wo + x / 2) * C + c);
     float4 o = make_float4(0.25f * v.x, 0.25f * v.y, 0.25f * v.z, 0.25f * v.w);
     if (accumulate) {
-      const float4 a = ld4(g + p * C + c);
+      const float4 a = ldA4<HS>(g, p * C + c);
       o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
     }
-    st4(g + p * C + c, o);
+    stA4<HS>(g, p * C + c, o);
   }
 }
 
 // adjoint of the bilinear x2 upsample, gather form (deterministic): every low-res pixel collects the
 // high-res pixels whose two source taps include it (output rows 2i-2 .. 2i+2 are the only candidates
 // because ratio < 1/2).
+template <bool HS>
 __global__ void up2x_bwd_kernel(const float* __restrict__ gu, float* __restrict__ g, int B, int Hin, int Win, int C) {
   SIFSR_CHAIN_PRIO();
   const int Q = C / 4, Ho = 2 * Hin, Wo = 2 * Win;
@@ -135,11 +141,11 @@ __global__ void up2x_bwd_kernel(const float* __restrict__ gu, float* __restrict_
         if (wx[kx] == 0.f) continue;
         const int ox = 2 * ix - 2 + kx;
         const float w = wy[ky] * wx[kx];
-        const float4 v = ld4(gu + (((size_t)b * Ho + oy) * Wo + ox) * C + c);
+        const float4 v = ldA4<HS>(gu, (((size_t)b * Ho + oy) * Wo + ox) * C + c);
         acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
       }
     }
-    st4(g + p * C + c, acc);
+    stA4<HS>(g, p * C + c, acc);
   }
 }
 
@@ -147,7 +153,7 @@ __global__ void up2x_bwd_kernel(const float* __restrict__ gu, float* __restrict_
 // Upsample: one workgroup = 16x16 output pixels.  Their <= 10x10 source pixels are loaded, BatchNorm+ReLU'd ONCE and
 // kept in LDS (the per-output form above transforms every source pixel four times and spends most of its time on
 // 64-bit index arithmetic); the blend itself is the same expression, so results are bit-identical.
-template <int C>
+template <int C, bool HS>
 __global__ __launch_bounds__(256) void bnrelu_up2x_tile_kernel(const float* __restrict__ y, const float* scale,
                                                                const float* shift, float* __restrict__ out, int Hin,
                                                                int Win) {
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256) void bnrelu_up2x_tile_kernel(const float* __re
     const int c4 = e % Q, p = e / Q;
     const int py = p / SR, px = p - py * SR;
     const int gy = min(sy0 + py, Hin - 1), gx = min(sx0 + px, Win - 1);
-    src[e] = maybe_bnrelu(ld4(y + ((size_t)(b * Hin + gy) * Win + gx) * C + 4 * c4), scale, shift, 4 * c4);
+    src[e] = maybe_bnrelu(ldA4<HS>(y, ((size_t)(b * Hin + gy) * Win + gx) * C + 4 * c4), scale, shift, 4 * c4);
   }
   __syncthreads();
   for (int e = tid; e < 256 * Q; e += 256) {
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256) void bnrelu_up2x_tile_kernel(const float* __re
     o.y = hy0 * (hx0 * v00.y + hx1 * v01.y) + hy1 * (hx0 * v10.y + hx1 * v11.y);
     o.z = hy0 * (hx0 * v00.z + hx1 * v01.z) + hy1 * (hx0 * v10.z + hx1 * v11.z);
     o.w = hy0 * (hx0 * v00.w + hx1 * v01.w) + hy1 * (hx0 * v10.w + hx1 * v11.w);
-    st4(out + ((size_t)(b * Ho + oy) * Wo + ox) * C + 4 * c4, o);
+    stA4<HS>(out, ((size_t)(b * Ho + oy) * Wo + ox) * C + 4 * c4, o);
   }
 }
 
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256) void bnrelu_up2x_tile_kernel(const float* __re
 // comes from ONE producer), so the workgroup also leaves that layer's BatchNorm-backward sums of its 8x8 pixels --
 // (sum dz, sum dz*y) per channel, dz = g*[y*scale + shift > 0] -- in row (b, by, bx) of bn_partials ([rows][C][2]); the
 // separate reduce pass over (g, y) is not launched (bn_bwd_finalize2 takes these sums).
-template <int C>
+template <int C, bool HS>
 __global__ __launch_bounds__(256) void up2x_bwd_tile_kernel(const float* __restrict__ gu, float* __restrict__ g, int Hin,
                                                             int Win, const float* __restrict__ bn_y,
                                                             const float* __restrict__ bn_scale,
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(256) void up2x_bwd_tile_kernel(const float* __restr
     const int py = p / HR, px = p - py * HR;
     const int oy = 2 * iy0 - 2 + py, ox = 2 * ix0 - 2 + px;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) v = ld4(gu + ((size_t)(b * Ho + oy) * Wo + ox) * C + ch0 + 4 * q);
+    if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) v = ldA4<HS>(gu, ((size_t)(b * Ho + oy) * Wo + ox) * C + ch0 + 4 * q);
     hi[e] = v;
   }
   __syncthreads();
@@ -254,11 +260,12 @@ __global__ __launch_bounds__(256) void up2x_bwd_tile_kernel(const float* __restr
       acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
     }
     const bool in = iy < Hin && ix < Win;
-    if (in) st4(g + ((size_t)(b * Hin + iy) * Win + ix) * C + ch0 + 4 * q, acc);
+    acc = as_stored4<HS>(acc);             // the sums below are those of the stored gradient
+    if (in) stA4<HS>(g, ((size_t)(b * Hin + iy) * Win + ix) * C + ch0 + 4 * q, acc);
     if (bn_partials != nullptr) {
       float4 d1 = make_float4(0.f, 0.f, 0.f, 0.f), d2 = d1;
       if (in) {
-        const float4 yv = ld4(bn_y + ((size_t)(b * Hin + iy) * Win + ix) * C + ch0 + 4 * q);
+        const float4 yv = ldA4<HS>(bn_y, ((size_t)(b * Hin + iy) * Win + ix) * C + ch0 + 4 * q);
         const float4 sc = ld4(bn_scale + ch0 + 4 * q), sh = ld4(bn_shift + ch0 + 4 * q);
         d1.x = fmaf(yv.x, sc.x, sh.x) > 0.f ? acc.x : 0.f; d2.x = d1.x * yv.x;
         d1.y = fmaf(yv.y, sc.y, sh.y) > 0.f ? acc.y : 0.f; d2.y = d1.y * yv.y;
@@ -300,14 +307,16 @@ inline int grid_for(size_t n) {
 
 int launch_bnrelu_pool2(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W, int C, hipStream_t s) {
   if (H % 2 || W % 2 || C % 4) return SIFSR_ERR_SHAPE;
-  hipLaunchKernelGGL(bnrelu_pool2_kernel, dim3(grid_for((size_t)B * H / 2 * W / 2 * C / 4)), dim3(256), 0, s, y, scale, shift, out, B, H, W, C);
+  if (sifsr_half_storage()) hipLaunchKernelGGL(bnrelu_pool2_kernel<true>, dim3(grid_for((size_t)B * H / 2 * W / 2 * C / 4)), dim3(256), 0, s, y, scale, shift, out, B, H, W, C);
+  else hipLaunchKernelGGL(bnrelu_pool2_kernel<false>, dim3(grid_for((size_t)B * H / 2 * W / 2 * C / 4)), dim3(256), 0, s, y, scale, shift, out, B, H, W, C);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
 int launch_bnrelu_add(const float* p, const float* y, const float* scale, const float* shift, float* out, int C, size_t npix, hipStream_t s) {
   if (C % 4) return SIFSR_ERR_SHAPE;
   const size_t nq = npix * C / 4;
-  hipLaunchKernelGGL(bnrelu_add_kernel, dim3(grid_for(nq)), dim3(256), 0, s, p, y, scale, shift, out, C, nq);
+  if (sifsr_half_storage()) hipLaunchKernelGGL(bnrelu_add_kernel<true>, dim3(grid_for(nq)), dim3(256), 0, s, p, y, scale, shift, out, C, nq);
+  else hipLaunchKernelGGL(bnrelu_add_kernel<false>, dim3(grid_for(nq)), dim3(256), 0, s, p, y, scale, shift, out, C, nq);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
@@ -315,19 +324,24 @@ int launch_bnrelu_up2x(const float* y, const float* scale, const float* shift, f
   if (C % 4) return SIFSR_ERR_SHAPE;
   if ((C == 16 || C == 32 || C == 64) && B <= 65535 && Hin >= 2 && Win >= 2) {
     const dim3 grid((2 * Win + 15) / 16, (2 * Hin + 15) / 16, B);
-    if (C == 16) hipLaunchKernelGGL((bnrelu_up2x_tile_kernel<16>), grid, dim3(256), 0, s, y, scale, shift, out, Hin, Win);
-    else if (C == 32) hipLaunchKernelGGL((bnrelu_up2x_tile_kernel<32>), grid, dim3(256), 0, s, y, scale, shift, out, Hin, Win);
-    else hipLaunchKernelGGL((bnrelu_up2x_tile_kernel<64>), grid, dim3(256), 0, s, y, scale, shift, out, Hin, Win);
+#define SIFSR_UP(CV, HV) hipLaunchKernelGGL((bnrelu_up2x_tile_kernel<CV, HV>), grid, dim3(256), 0, s, y, scale, shift, out, Hin, Win)
+    const bool hs = sifsr_half_storage();
+    if (C == 16) { if (hs) SIFSR_UP(16, true); else SIFSR_UP(16, false); }
+    else if (C == 32) { if (hs) SIFSR_UP(32, true); else SIFSR_UP(32, false); }
+    else { if (hs) SIFSR_UP(64, true); else SIFSR_UP(64, false); }
+#undef SIFSR_UP
     SIFSR_LAUNCH_CHECK();
     return SIFSR_OK;
   }
-  hipLaunchKernelGGL(bnrelu_up2x_kernel, dim3(grid_for((size_t)B * Hin * Win * C)), dim3(256), 0, s, y, scale, shift, out, B, Hin, Win, C);
+  if (sifsr_half_storage()) hipLaunchKernelGGL(bnrelu_up2x_kernel<true>, dim3(grid_for((size_t)B * Hin * Win * C)), dim3(256), 0, s, y, scale, shift, out, B, Hin, Win, C);
+  else hipLaunchKernelGGL(bnrelu_up2x_kernel<false>, dim3(grid_for((size_t)B * Hin * Win * C)), dim3(256), 0, s, y, scale, shift, out, B, Hin, Win, C);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
 int launch_pool2_bwd(const float* gp, float* g, int B, int H, int W, int C, int accumulate, hipStream_t s) {
   if (H % 2 || W % 2 || C % 4) return SIFSR_ERR_SHAPE;
-  hipLaunchKernelGGL(pool2_bwd_kernel, dim3(grid_for((size_t)B * H * W * C / 4)), dim3(256), 0, s, gp, g, B, H, W, C, accumulate);
+  if (sifsr_half_storage()) hipLaunchKernelGGL(pool2_bwd_kernel<true>, dim3(grid_for((size_t)B * H * W * C / 4)), dim3(256), 0, s, gp, g, B, H, W, C, accumulate);
+  else hipLaunchKernelGGL(pool2_bwd_kernel<false>, dim3(grid_for((size_t)B * H * W * C / 4)), dim3(256), 0, s, gp, g, B, H, W, C, accumulate);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
@@ -342,13 +356,17 @@ int launch_up2x_bwd(const float* gu, float* g, int B, int Hin, int Win, int C, h
   if (bn_partials != nullptr && (!bn_y || !bn_scale || !bn_shift || up2x_bwd_stat_rows(B, Hin, Win, C) == 0)) return SIFSR_ERR_ARG;
   if ((C == 16 || C == 32 || C == 64) && (size_t)B * (C / 16) <= 65535) {
     const dim3 grid((Win + 7) / 8, (Hin + 7) / 8, B * (C / 16));
-    if (C == 16) hipLaunchKernelGGL((up2x_bwd_tile_kernel<16>), grid, dim3(256), 0, s, gu, g, Hin, Win, bn_y, bn_scale, bn_shift, bn_partials);
-    else if (C == 32) hipLaunchKernelGGL((up2x_bwd_tile_kernel<32>), grid, dim3(256), 0, s, gu, g, Hin, Win, bn_y, bn_scale, bn_shift, bn_partials);
-    else hipLaunchKernelGGL((up2x_bwd_tile_kernel<64>), grid, dim3(256), 0, s, gu, g, Hin, Win, bn_y, bn_scale, bn_shift, bn_partials);
+#define SIFSR_UPB(CV, HV) hipLaunchKernelGGL((up2x_bwd_tile_kernel<CV, HV>), grid, dim3(256), 0, s, gu, g, Hin, Win, bn_y, bn_scale, bn_shift, bn_partials)
+    const bool hs = sifsr_half_storage();
+    if (C == 16) { if (hs) SIFSR_UPB(16, true); else SIFSR_UPB(16, false); }
+    else if (C == 32) { if (hs) SIFSR_UPB(32, true); else SIFSR_UPB(32, false); }
+    else { if (hs) SIFSR_UPB(64, true); else SIFSR_UPB(64, false); }
+#undef SIFSR_UPB
     SIFSR_LAUNCH_CHECK();
     return SIFSR_OK;
   }
-  hipLaunchKernelGGL(up2x_bwd_kernel, dim3(grid_for((size_t)B * Hin * Win * C / 4)), dim3(256), 0, s, gu, g, B, Hin, Win, C);
+  if (sifsr_half_storage()) hipLaunchKernelGGL(up2x_bwd_kernel<true>, dim3(grid_for((size_t)B * Hin * Win * C / 4)), dim3(256), 0, s, gu, g, B, Hin, Win, C);
+  else hipLaunchKernelGGL(up2x_bwd_kernel<false>, dim3(grid_for((size_t)B * Hin * Win * C / 4)), dim3(256), 0, s, gu, g, B, Hin, Win, C);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
