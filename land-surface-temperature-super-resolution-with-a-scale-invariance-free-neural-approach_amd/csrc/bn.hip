@@ -66,9 +66,11 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ params, const fl
 struct PoolAdj { const float* gp; int H, W; };
 template <int C, bool HS = false>
 __device__ __forceinline__ float4 pool_adj4(const PoolAdj pa, size_t p, int c4) {
-  const unsigned W = (unsigned)pa.W, H = (unsigned)pa.H;
-  const unsigned x = (unsigned)(p % W), r = (unsigned)(p / W);
-  const unsigned yy = r % H, b = r / H;
+  // 32-bit index arithmetic (p < 2^28: the launchers keep every tensor below 2^32 bytes): the 64-bit divisions that stood here
+  // cost ~300 instructions per element and made the kernel compute-bound once bf16 storage halved its bytes
+  const unsigned W = (unsigned)pa.W, H = (unsigned)pa.H, p32 = (unsigned)p;
+  const unsigned r = p32 / W, x = p32 - r * W;
+  const unsigned b = r / H, yy = r - b * H;
   const float4 v = ldA4<HS>(pa.gp, (((size_t)b * (H / 2) + yy / 2) * (W / 2) + x / 2) * C + 4 * c4);
   return make_float4(0.25f * v.x, 0.25f * v.y, 0.25f * v.z, 0.25f * v.w);
 }

@@ -1,6 +1,7 @@
 // Argument blocks of the 3x3 convolution kernels (internal; the C-ABI is include/sifsr_hip.h).
 #pragma once
 #include "common.h"
+#include "diag.h"
 
 // One input operand of a conv: channels [coff, coff + 16*nq) of an NHWC tensor with C channels.
 // scale/shift != nullptr: the tensor is a RAW conv output and relu(x*scale[c]+shift[c]) (the folded

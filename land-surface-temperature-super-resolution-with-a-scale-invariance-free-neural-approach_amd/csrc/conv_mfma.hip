@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
   if (producer) {
     // =========================================== PRODUCER ===========================================
     // 16-output-channel Winograd layers (the HBM-heaviest ones): the PRODUCERS take the higher priority.  Without the MFMA work
-    // the same data movement runs at 5.5 TB/s (100 us for 16->16 @256^2, SIFSR_DBG_NOMFMA build); with it 150 us although the
+    // the same data movement runs at 5.5 TB/s (100 us for 16->16 @256^2, SIFSR_DIAG_NOMFMA build, diag.h); with it 150 us although the
     // matrix work alone is ~75 us -- the consumers' back-to-back MFMAs keep the producers' few staging instructions and the next
     // item's loads from issuing on time.  Producers at 3, consumers at 2: -4 % forward, -6 % input gradient, +0.9 % on the step.
     // (the bf16-operand kernels, HBM-bound throughout, take the same arrangement: +0.8 % on the bf16 step)
@@ -212,11 +212,7 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
     // DEPTH register sets = DEPTH items in flight: the loads of item j + DEPTH are issued when item j goes to LDS.  One is
     // enough everywhere: with two or three sets the one-workgroup-per-CU Winograd variants (whose items are half as long)
     // measured the same to 0.2 % -- what they wait for is not load latency.
-#ifdef SIFSR_DBG_DEPTH_LEAN
-    constexpr int DEPTH = (WINO && NB == 1 && !ZERO_PAD) ? SIFSR_DBG_DEPTH_LEAN : 1;
-#else
     constexpr int DEPTH = 1;
-#endif
     float4 stgS[DEPTH][6], scS[DEPTH], shS[DEPTH];
     float4 styS[DYF ? DEPTH : 1][DYF ? 6 : 1], k1S[DEPTH], k0S[DEPTH];   // DYF: y of the same slots, two more coefficient quads
     bool rawS[DEPTH];
@@ -419,9 +415,7 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
 
       const float4* L = lds[buf];
       __builtin_amdgcn_s_setprio(NB == 1 ? 2 : 3);   // NB == 1: below this kernel's producers (see there)
-#ifdef SIFSR_DBG_NOMFMA
-      if (a.B < 0)   // diagnostic build: the kernel's data movement without its matrix work (results are zeros)
-#endif
+      SIFSR_DIAG_SKIP_MATRIX_WORK(a.B < 0)   // (diag.h: nothing in the shipped build)
 #pragma unroll
       for (int g = 0; g < NGRP; ++g) {
         // ---- the patch's 4x4 input window -> V = B^T d B (in place).  Every float4 is handled as its two aligned

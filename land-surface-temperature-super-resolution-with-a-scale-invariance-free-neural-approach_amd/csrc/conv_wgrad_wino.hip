@@ -199,9 +199,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_kernel(const WgradArgs
     const int next = tile + gridDim.x;
     if (next < a.ntiles) issue(next);     // in flight during the MFMA phase below
 
-#ifdef SIFSR_DBG_NOMFMA
-    if (a.B < 0)   // diagnostic build: the kernel's data movement without its matrix work (results are zeros)
-#endif
+    SIFSR_DIAG_SKIP_MATRIX_WORK(a.B < 0)   // (diag.h: nothing in the shipped build)
 #pragma unroll
     for (int j = 0; j < KSW; ++j) {
       const int h = wp + WP * j;                 // k-step: patch row h >> 1, patch columns 4 * (h & 1) + (0..3)

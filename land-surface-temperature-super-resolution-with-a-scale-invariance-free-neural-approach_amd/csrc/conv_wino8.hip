@@ -19,10 +19,7 @@
 
 #include <stdlib.h>
 
-#ifdef SIFSR_CLOCK_STAMP
-// Diagnostic build only (tools/clock_probe.py): shader-clock and 100 MHz stamps around the item loop, summed over workgroups.
-__device__ unsigned long long sifsr_clk[4];
-#endif
+SIFSR_DIAG_CLOCK_DECL   // (diag.h: nothing in the shipped build)
 namespace {
 
 constexpr int PW = 18;
@@ -241,9 +238,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
   for (int i = 1; i <= DEPTH; ++i) issue_loads(i % DEPTH);   // item i lives in set i % DEPTH
   __syncthreads();
 
-#ifdef SIFSR_CLOCK_STAMP
-  const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), cr0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  SIFSR_DIAG_CLOCK_BEGIN
   int buf = 0, q = 0;
   auto do_item = [&](const int j, const int ks) {   // ks = (j + 1) % DEPTH: the register set of item j + 1
     const bool last_q = q + 1 == NQ;
@@ -264,9 +259,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
       issue_loads(ks);          // item j + 1 + DEPTH
     }
     __builtin_amdgcn_s_setprio(2);
-#ifdef SIFSR_DBG_NOMFMA
-    if (a.B < 0)   // diagnostic build: the kernel's data movement without its matrix work (results are zeros)
-#endif
+    SIFSR_DIAG_SKIP_MATRIX_WORK(a.B < 0)   // (diag.h: nothing in the shipped build)
 #pragma unroll
     for (int g = 0; g < NGRP; ++g) {
       // ---- the patch's 4x4 input window -> V = B^T d B (in place), as conv_mfma.hip's Winograd consumer
@@ -378,12 +371,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
       if (j + k < n_items) do_item(j + k, (k + 1) % DEPTH);   // uniform over the workgroup
   }
 
-#ifdef SIFSR_CLOCK_STAMP
-  {
-    const unsigned long long ck1 = __builtin_amdgcn_s_memtime(), cr1 = __builtin_amdgcn_s_memrealtime();
-    if (tid == 0) { atomicAdd(&sifsr_clk[0], ck1 - ck0); atomicAdd(&sifsr_clk[1], cr1 - cr0); }
-  }
-#endif
+  SIFSR_DIAG_CLOCK_END(tid)
   // ---- per-workgroup BatchNorm partials (sum, sum of squares) over all tiles this workgroup produced ----
   if (a.stat_partials != nullptr) {
     const int px = lane & 15;
@@ -435,10 +423,4 @@ int launch_conv3x3_wino8(const ConvArgs& a, int nb, int zero_pad, bool dyf, int 
   return SIFSR_ERR_SHAPE;
 }
 
-#ifdef SIFSR_CLOCK_STAMP
-extern "C" __attribute__((visibility("default"))) int sifsr_debug_timers(unsigned long long* out4, int reset) {
-  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(sifsr_clk), 32) != hipSuccess) return 1;
-  if (reset) { unsigned long long z[4] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sifsr_clk), z, 32) != hipSuccess) return 2; }
-  return 0;
-}
-#endif
+SIFSR_DIAG_CLOCK_READER

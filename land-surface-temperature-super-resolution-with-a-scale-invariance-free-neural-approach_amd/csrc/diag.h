@@ -1,0 +1,37 @@
+// Diagnostic build flavours of the MFMA kernels -- ONE place for every switch that changes what a kernel does in a
+// non-shipping build.  The shipped library is built with none of them defined; tests/test_diag_builds.py compiles each flavour
+// once (CPU box, no GPU needed) so that they keep building, and tools/build_ab.sh NAME -D... makes an A/B library of one.
+//
+//   -DSIFSR_DIAG_NOMFMA    the conv kernels without their window reads, transforms and MFMAs (results are zeros): what a kernel's
+//                          data movement alone costs (tools/nomfma_sweep.sh, profiles/r02_nomfma_sweep.txt)
+//   -DSIFSR_DIAG_CLOCK     shader-clock / 100 MHz stamps around the item loop of conv3x3_wino8_kernel, read back through
+//                          sifsr_debug_timers() (tools/clock_probe.py: the in-kernel clock under load)
+//   -DSIFSR_PK_MODE=0..3   form of the packed add / subtract of the Winograd transforms (common.h; 0 ships)
+#pragma once
+
+#ifdef SIFSR_DIAG_NOMFMA
+#define SIFSR_DIAG_SKIP_MATRIX_WORK(never_true) if (never_true)
+#else
+#define SIFSR_DIAG_SKIP_MATRIX_WORK(never_true)
+#endif
+
+#ifdef SIFSR_DIAG_CLOCK
+#define SIFSR_DIAG_CLOCK_DECL __device__ unsigned long long sifsr_clk[4];
+#define SIFSR_DIAG_CLOCK_BEGIN const unsigned long long ck0__ = __builtin_amdgcn_s_memtime(), cr0__ = __builtin_amdgcn_s_memrealtime();
+#define SIFSR_DIAG_CLOCK_END(tid)                                                                       \
+  {                                                                                                     \
+    const unsigned long long ck1__ = __builtin_amdgcn_s_memtime(), cr1__ = __builtin_amdgcn_s_memrealtime(); \
+    if ((tid) == 0) { atomicAdd(&sifsr_clk[0], ck1__ - ck0__); atomicAdd(&sifsr_clk[1], cr1__ - cr0__); }   \
+  }
+#define SIFSR_DIAG_CLOCK_READER                                                                                          \
+  extern "C" __attribute__((visibility("default"))) int sifsr_debug_timers(unsigned long long* out4, int reset) {        \
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(sifsr_clk), 32) != hipSuccess) return 1;                                    \
+    if (reset) { unsigned long long z[4] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sifsr_clk), z, 32) != hipSuccess) return 2; } \
+    return 0;                                                                                                            \
+  }
+#else
+#define SIFSR_DIAG_CLOCK_DECL
+#define SIFSR_DIAG_CLOCK_BEGIN
+#define SIFSR_DIAG_CLOCK_END(tid)
+#define SIFSR_DIAG_CLOCK_READER
+#endif

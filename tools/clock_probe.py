@@ -1,6 +1,6 @@
 """In-kernel clock of the eight-wave Winograd kernel (debugging build with s_memtime / s_memrealtime stamps around the item loop):
 shader cycles per 100 MHz tick, summed over workgroups.  MI355X_MICROARCH.md, 'DVFS give-back' item 6.
-  bash tools/build_variant.sh clk conv_wino8.hip -DSIFSR_CLOCK_STAMP
+  bash tools/build_ab.sh clk -DSIFSR_DIAG_CLOCK
   SIFSR_LIB=$PWD/tools/ab/libsifsr_clk.so python tools/clock_probe.py fwd 64 32 128
 Round 2: 2.34-2.38 GHz (forward 64->32 @128^2, 128->64 @64^2, input gradient 32<-64 @128^2) -- the chip does not hold its clock
 down under these kernels; after >= 2 s of back-to-back launches on the same tensors a launch takes 204 us where the 10-launch

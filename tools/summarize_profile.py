@@ -45,53 +45,56 @@ for r in rows[:30]:
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 
-# ---- per-launch HBM traffic of the kernels bench.py can select as its roofline kernel ----
-# The n-th launch of a kernel inside a step is identified by dispatch order (the schedule is static):
-#   fwd <1,false>: [inbloc.3, db1.res.0, db1.res.3, ub2.3, ub3.0, ub3.3]; dgrad <1,true> (backward order):
-#   [ub3.3, ub2.3, db1.lastconv?...] -- only the unambiguous first/last launches are exported.
-def per_launch(kind, pattern, nth, per_step):
-    f = glob.glob(f"{src}/pmc_{kind}/*/*counter_collection.csv")
-    if not f:
-        return None
-    vals = [float(r["Counter_Value"]) for r in sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Dispatch_Id"]))
-            if pattern in r["Kernel_Name"]]
-    if len(vals) < per_step * steps:
-        return None
-    picks = [vals[i * per_step + nth] for i in range(steps)]
-    return sum(picks) / len(picks)
-
-
+# ---- per-class HBM traffic (what bench.py reports as roofline.traffic): the average bytes per launch of every kernel class of
+# bench.class_table(), from the two PMC passes, and the whole step ----
 import json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench   # noqa: E402  (class table only; bench.py imports torch lazily)
+
+def pmc_rows(kind):
+    f = glob.glob(f"{src}/pmc_{kind}/*/*counter_collection.csv")
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+frows, wrows = pmc_rows("fetch"), pmc_rows("write")
+classes = sorted(bench.class_table(), key=len, reverse=True)      # longest prefix first
+def class_of(name):
+    for c in classes:
+        if c in name:
+            return c
+    return None
 traffic = {}
-for name, pattern, nth, per_step in [
-        ("fwd_16x16_256", "conv3x3_mfma_kernel<1, false,", 0, 6),     # inbloc.bloc.3: first <1,false> launch of a step
-        ("fwd_32x16_256", "conv3x3_mfma_kernel<1, false,", 4, 6),     # ub3.convbloc.bloc.0
-        ("dgrad_16x16_256", "conv3x3_mfma_kernel<1, true,", 4, 5),    # inbloc.bloc.3: last 16-channel dgrad of the backward
-        ("wgrad_16x16_256", "conv3x3_wgrad_wino_kernel<1, 1, true>", 2, 3)]:     # inbloc.bloc.3 (after the two 128^2 layers)
-    fr, wr = per_launch("fetch", pattern, nth, per_step), per_launch("write", pattern, nth, per_step)
-    if fr is not None and wr is not None:
-        traffic[name] = {"read_bytes": 2 * fr * 1024, "write_bytes": wr * 1024, "bytes": 2 * fr * 1024 + wr * 1024}
-# per-launch durations of the same launches from the kernel trace (what bench.py's HIP-event timing must agree with)
+for c in classes:
+    fr = [float(r["Counter_Value"]) for r in frows if class_of(r["Kernel_Name"]) == c]
+    wr = [float(r["Counter_Value"]) for r in wrows if class_of(r["Kernel_Name"]) == c]
+    if fr and wr:
+        rb, wb = 2 * 1024 * sum(fr) / len(fr), 1024 * sum(wr) / len(wr)
+        traffic[c] = {"read_bytes": rb, "write_bytes": wb, "bytes": rb + wb, "launches_profiled": len(fr)}
+tot_r = 2 * 1024 * sum(float(r["Counter_Value"]) for r in frows) / steps
+tot_w = 1024 * sum(float(r["Counter_Value"]) for r in wrows) / steps
 trace = glob.glob(f"{src}/stats/*/*kernel_trace.csv")
 if trace:
-    trows = sorted(csv.DictReader(open(trace[0])), key=lambda r: int(r["Start_Timestamp"]))
-    for name, pattern, nth, per_step in [("fwd_16x16_256", "conv3x3_mfma_kernel<1, false,", 0, 6), ("fwd_32x16_256", "conv3x3_mfma_kernel<1, false,", 4, 6),
-                                         ("dgrad_16x16_256", "conv3x3_mfma_kernel<1, true,", 4, 5), ("wgrad_16x16_256", "conv3x3_wgrad_wino_kernel<1, 1, true>", 2, 3)]:
-        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trows if pattern in r["Kernel_Name"]]
-        if len(d) >= per_step * steps and name in traffic:
-            pick = d[nth::per_step][:steps]
-            traffic[name]["avg_us_rocprofv3"] = sum(pick) / len(pick)
-    with open(f"profiles/{tag}_summary.md", "a") as fh:
-        fh.write("\n| roofline kernel (one launch) | avg µs (kernel trace) | HBM read MB | HBM write MB |\n|---|---|---|---|\n")
-        for name, t in traffic.items():
-            fh.write("| `%s` | %.1f | %.1f | %.1f |\n" % (name, t.get("avg_us_rocprofv3", float("nan")), t["read_bytes"] / 1e6, t["write_bytes"] / 1e6))
+    trows = list(csv.DictReader(open(trace[0])))
+    for c in traffic:
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trows if class_of(r["Kernel_Name"]) == c]
+        if d:
+            traffic[c]["avg_us_rocprofv3"] = sum(d) / len(d)
+with open(f"profiles/{tag}_summary.md", "a") as fh:
+    fh.write("\n| kernel class | launches/step | avg µs (kernel trace) | HBM read MB / launch | HBM write MB / launch |\n|---|---|---|---|---|\n")
+    for c, t in traffic.items():
+        fh.write("| `%s>` | %d | %.1f | %.1f | %.1f |\n" % (c, len(bench.class_table()[c]), t.get("avg_us_rocprofv3", float("nan")), t["read_bytes"] / 1e6, t["write_bytes"] / 1e6))
+    if frows and wrows:
+        alg = bench.TRAIN_BYTES_PER_PATCH * 64
+        fh.write("\nWhole step (all kernels, PMC): %.2f GB read + %.2f GB written = **%.2f GB = %.2fx the algorithmic %.2f GB** (SURVEY.md section 8 d).\n"
+                 % (tot_r / 1e9, tot_w / 1e9, (tot_r + tot_w) / 1e9, (tot_r + tot_w) / alg, alg / 1e9))
 json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tag {tag}; FETCH_SIZE doubled (gfx950)",
+           "step": {"read_bytes": tot_r, "write_bytes": tot_w, "bytes": tot_r + tot_w, "algorithmic_bytes": bench.TRAIN_BYTES_PER_PATCH * 64},
            "per_launch": traffic}, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 
 # ---- category roll-up ----
 cats = collections.OrderedDict([
     ("conv fwd (MFMA)", lambda k: any(t in k and k.split(t)[1].split(",")[1].strip().startswith("false") for t in ("conv3x3_mfma_kernel<", "conv3x3_wino8_kernel<"))),
+    ("conv dgrad + wgrad, one kernel (16->16 layers)", lambda k: "conv3x3_bwd16" in k),
     ("conv dgrad (MFMA)", lambda k: any(t in k and k.split(t)[1].split(",")[1].strip().startswith("true") for t in ("conv3x3_mfma_kernel<", "conv3x3_wino8_kernel<"))),
     ("dgrad border", lambda k: "dgrad_border" in k),
     ("conv wgrad (MFMA)", lambda k: "conv3x3_wgrad" in k),
