@@ -239,6 +239,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
         for (int o = 0; o < 4; ++o)
           yq[o] = bl4(rby, (unsigned)((cb * H + y0_ + (o >> 1)) * W + x0_ + (o & 1)) * 64u + (unsigned)kq * 16u, 0u);
       }
+      f32x4 Y[2][2] = {{zero4, zero4}, {zero4, zero4}};
+      SIFSR_DIAG_SKIP_MATRIX_WORK(a.B < 0) {   // (diag.h: nothing in the shipped build)
       f32x2 dl[4][4], dh[4][4];
       const float4* Lg = dyq[buf] + lbase;
 #pragma unroll
@@ -263,7 +265,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
         dl[r][0] = l0; dl[r][1] = l1; dl[r][2] = l2; dl[r][3] = l3;
         dh[r][0] = h0; dh[r][1] = h1; dh[r][2] = h2; dh[r][3] = h3;
       }
-      f32x4 Y[2][2] = {{zero4, zero4}, {zero4, zero4}};
 #pragma unroll
       for (int ar = 0; ar < 4; ++ar) {
         f32x4 Mc[4];
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
         if (ar <= 2) { acc2(Y[0][0], t0l, t0h, false); acc2(Y[0][1], t1l, t1h, false); }
         if (ar == 1) { acc2(Y[1][0], t0l, t0h, false); acc2(Y[1][1], t1l, t1h, false); }
         if (ar >= 2) { acc2(Y[1][0], t0l, t0h, true); acc2(Y[1][1], t1l, t1h, true); }
+      }
       }
       // ---- epilogue: the lane's 2x2 output pixels x 4 input channels
 #pragma unroll
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
       // ======================= weight gradient: Winograd F(3x3,2x2), 4 k-steps (of 4 patches) per wave =======================
       const float* const pa = dyp[buf] + pa_off;
       const float* const pb = xp[buf] + pb_off;
+      SIFSR_DIAG_SKIP_MATRIX_WORK(a.B < 0)   // (diag.h: nothing in the shipped build)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int h = wave + 4 * j;                       // k-step: patch row h >> 1 (0..7), patch columns 4 (h & 1) + (0..3)

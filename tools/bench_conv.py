@@ -1,5 +1,6 @@
 """Micro-benchmark of single conv ops through the C ABI (for PMC / tuning).
-usage: python tools/bench_conv.py [fwd|dgrad|wgrad|wgradx] [cin] [cout] [H] [B] [iters]   (wgradx = Winograd F(3x3,2x2) weight gradient)"""
+usage: python tools/bench_conv.py [fwd|dgrad|wgrad|wgradx|bwd16] [cin] [cout] [H] [B] [iters]   (wgradx = Winograd F(3x3,2x2) weight gradient;
+       bwd16 = input + weight gradient of a 16 -> 16 layer in one kernel, with dL/dy formed on load and the fused BatchNorm sums)"""
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sifsr
 from sifsr import _lib as L
@@ -29,8 +30,17 @@ scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_scratch_floats", cin, cout, nb
 dw = torch.empty_like(w)
 if op == "wgradx":
     scratch = torch.empty(L.call("sifsr_conv3x3_wgrad_wino_scratch_floats", cin, cout, nblk), device=dev)
+if op == "bwd16":
+    assert cin == 16 and cout == 16
+    ycur = torch.randn(B, H, H, 16, device=dev); coef = torch.randn(64, device=dev) * 0.1 + 0.5
+    border = torch.empty(B, H, H, 16, device=dev)
+    rows = L.call("sifsr_conv3x3_bwd16_stat_rows", B, H, H)
+    bnp = torch.empty(rows * 32, device=dev)
+    scratch = torch.empty(L.call("sifsr_conv3x3_bwd16_scratch_floats", B, H, H), device=dev)
 def run():
-    if op == "fwd" and mode == "wino":
+    if op == "bwd16":
+        L.call("sifsr_conv3x3_bwd16", x, sc, sh, dy, ycur, coef, border, wd, wwd, g, None, x, sc, sh, bnp, scratch, dw, B, H, H, S)
+    elif op == "fwd" and mode == "wino":
         L.call("sifsr_conv3x3_fwd_wino", x, cin, sc, sh, None, 0, None, None, wf, wwf, y, cout, part, B, H, H, S)
     elif op == "dgrad" and mode == "wino":
         L.call("sifsr_conv3x3_dgrad_wino", dy, cout, wd, wwd, cin, g, cin, None, 0, None, B, H, H, S)
@@ -53,5 +63,5 @@ e0.record()
 for _ in range(iters): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
-fl = 2 * 9 * cin * cout * H * H * B
+fl = 2 * 9 * cin * cout * H * H * B * (2 if op == "bwd16" else 1)
 print(f"[{mode}] {op} {cin}->{cout} @{H}^2 B={B}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s ({fl/ms/1e9/157.3*100:.1f}% of fp32 MFMA peak)")
