@@ -15,7 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 PMC="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/cal -- $OUT/mfma_peak > $OUT/cal.log 2>&1 || { tail -5 $OUT/cal.log; exit 1; }
 echo "calibration pass done"
-rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/step -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-solo > $OUT/step.log 2>&1 || { tail -5 $OUT/step.log; exit 1; }
+rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/step -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-solo --no-also > $OUT/step.log 2>&1 || { tail -5 $OUT/step.log; exit 1; }
 echo "step pass done"
 cd $ROOT && python3 tools/pmc_mfma_summary.py $OUT > $OUT/summary.txt && cat $OUT/summary.txt
 rm -f $OUT/mfma_peak
