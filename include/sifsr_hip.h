@@ -144,8 +144,8 @@ SIFSR_API int sifsr_conv3x3_wgrad_wino(const float* src0, int C0, const float* s
  * shape error otherwise: use sifsr_conv3x3_dgrad_fused / _dgrad_wino + sifsr_conv3x3_wgrad_wino).
  *   y == coef_f == NULL: g is dL/dy itself (border unused); otherwise g, y, coef_f, border as for sifsr_conv3x3_dgrad_fused.
  *   gin = conv^T(dL/dy) incl. the replicate-border fold (+ addend);  dw = OIHW weight gradient (16,16,3,3).
- *   bn_partials != NULL: gin is the gradient w.r.t. relu(bn(bn_y)) of the layer below (raw conv output bn_y, folded BatchNorm
- *   bn_scale / bn_shift) and its BatchNorm-backward sums are emitted as sifsr_conv3x3_bwd16_stat_rows() rows of [16][2]
+ *   bn_partials != NULL: gin is the gradient w.r.t. relu(bn(bn_y)) of the layer below -- bn_y, bn_scale, bn_shift must BE x, x_scale,
+ *   x_shift (the layer below is the layer whose raw output is this layer's input) -- and its BatchNorm-backward sums are emitted as sifsr_conv3x3_bwd16_stat_rows() rows of [16][2]
  *   (sum dz, sum dz*y per channel; dz = gin*[bn_y*scale+shift > 0]); add the rows up.  Not together with addend.
  *   scratch: sifsr_conv3x3_bwd16_scratch_floats() floats (weight-gradient slabs + their float64 sum). */
 SIFSR_API int sifsr_conv3x3_bwd16_stat_rows(int B, int H, int W);

@@ -11,7 +11,7 @@
 //   waves 0-3  input gradient,  Winograd F(2x2,3x3): the consumer of conv_mfma.hip (lane = (patch, cout quad); 16 ds_read_b128 of
 //              the patch's 4x4 window, input transform in registers, 64 MFMAs per 16-patch group, output transform per xi-row),
 //              transform-domain weights in LDS; epilogue = NHWC stores (+ residual addend) and the BatchNorm-backward sums of the
-//              layer below (its y requested before the MFMAs);
+//              layer below (its raw y is the staged input tile in LDS);
 //   waves 4-7  weight gradient, Winograd F(3x3,2x2): the per-lane register transforms of conv_wgrad_wino.hip (lane = (channel,
 //              patch of a 4-patch k-step); 2 + 8 ds_read_b64 from channel planes, 16 MFMAs per k-step, 4 k-steps per wave and
 //              tile), accumulators live across all tiles, added up through LDS into one slab per workgroup at the end.
@@ -22,6 +22,8 @@
 #include "conv.h"
 
 #include <stdlib.h>
+
+SIFSR_DIAG_CLOCK16_DECL   // (diag.h: nothing in the shipped build; tools/clock_probe16.py reads the per-phase clock sums)
 
 namespace {
 
@@ -102,8 +104,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
   float4 csc = make_float4(0.f, 0.f, 0.f, 0.f), csh = csc, ck1 = csc, ck0 = csc;
   if (DYF) { csc = ld4(a.coef + 4 * cg); csh = ld4(a.coef + 16 + 4 * cg); ck1 = ld4(a.coef + 32 + 4 * cg); ck0 = ld4(a.coef + 48 + 4 * cg); }
   const bool xraw = a.x_scale == nullptr;
-  float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!xraw) { xsc = ld4(a.x_scale + 4 * cg); xsh = ld4(a.x_shift + 4 * cg); }
 
   float4 pg[3], py[DYF ? 3 : 1], px_[3];                 // the tile in flight
   int st_b = 0, st_tx = 0, st_ty = 0;                     // ... and its position
@@ -157,9 +157,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
         float* d = P + lp[it];
         d[0] = v.x; d[4 * DPS] = v.y; d[8 * DPS] = v.z; d[12 * DPS] = v.w;   // channel 4 cg + r -> plane cg + 4 r
       }
-      float4 xv = px_[it];
-      if (!xraw) xv = bn_relu4(xv, xsc, xsh);
-      float* e = X + lx[it];
+      const float4 xv = px_[it];   // RAW: the weight-gradient waves apply the folded BatchNorm + ReLU when they read their windows (they
+      float* e = X + lx[it];      // have the issue slots to spare), the input-gradient waves read y_below itself for the BatchNorm sums
       e[0] = xv.x; e[4 * XPS] = xv.y; e[8 * XPS] = xv.z; e[12 * XPS] = xv.w;
     }
   };
@@ -174,13 +173,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
   const __amdgpu_buffer_rsrc_t rd = mk_rsrc(a.gin, npix * 64u);
   const __amdgpu_buffer_rsrc_t rad = mk_rsrc(a.addend ? a.addend : a.gin, npix * 64u);
   const bool bn_stats = a.bn_y != nullptr;
-  const __amdgpu_buffer_rsrc_t rby = mk_rsrc(bn_stats ? a.bn_y : a.gin, npix * 64u);
   float4 bsc = make_float4(0.f, 0.f, 0.f, 0.f), bsh = bsc;
   if (bn_stats) { bsc = ld4(a.bn_scale + 4 * kq); bsh = ld4(a.bn_shift + 4 * kq); }
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   // ---- weight-gradient state (the accumulators are declared in the weight-gradient branch)
   const int pa_off = xslot(i16) * DPS + 2 * kq;           // my dy plane, my patch of a k-step (kq = patch of the 4)
   const int pb_off = xslot(i16) * XPS + 2 * kq;
+  // folded BatchNorm of the layer below for MY input channel (lane i16 of the B operand): a_in = relu(x * xs + xb)
+  const f32x2 xs2 = xraw ? (f32x2){1.f, 1.f} : (f32x2){a.x_scale[i16], a.x_scale[i16]};
+  const f32x2 xb2 = xraw ? (f32x2){0.f, 0.f} : (f32x2){a.x_shift[i16], a.x_shift[i16]};
 
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto lo2 = [](f32x4 v) { return (f32x2){v[0], v[1]}; };
@@ -212,17 +213,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
       const int t_next = t + t_step;
       const bool more = t_next < t_hi;
       const int nb_ = st_b, ntx_ = st_tx, nty_ = st_ty;   // position of tile j+1 (in flight)
+      const int ro_ = stage_first ? 0 : 4;
+      (void)ro_;
+      SIFSR_DIAG_T(c0);
       if (stage_first && more) {
+        SIFSR_DIAG_WAIT_LOADS(cw);
+        SIFSR_DIAG_ACC16(8, cw);
         write_stage(buf ^ 1);
         if (t_next + t_step < t_hi) issue(t_next + t_step);
       }
+      SIFSR_DIAG_T(c1);
       contract(buf, cb, txi, tyi);
+      SIFSR_DIAG_T(c2);
       if (!stage_first && more) {
+        SIFSR_DIAG_WAIT_LOADS(cw);
+        SIFSR_DIAG_ACC16(9, cw);
         write_stage(buf ^ 1);
         if (t_next + t_step < t_hi) issue(t_next + t_step);
       }
+      SIFSR_DIAG_T(c3);
       if (!more) break;
       __syncthreads();
+      SIFSR_DIAG_T(c4);
+      SIFSR_DIAG_ACC16(ro_ + 0, (c1 - c0) + (c3 - c2)); SIFSR_DIAG_ACC16(ro_ + 1, c2 - c1); SIFSR_DIAG_ACC16(ro_ + 2, c4 - c3); SIFSR_DIAG_ACC16(ro_ + 3, 1);
       cb = nb_; txi = ntx_; tyi = nty_;
       t = t_next;
       buf ^= 1;
@@ -232,13 +245,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
   if (dgrad_role) {
     tile_loop(true, [&](const int buf, const int cb, const int txi, const int tyi) {
       // ======================= input gradient: Winograd F(2x2,3x3), one 16-patch group (4 tile rows) per wave =======================
-      float4 yq[4];
-      if (bn_stats) {
-        const int y0_ = tyi * 16 + g0 + 2 * pyl, x0_ = txi * 16 + 2 * pxp;
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-          yq[o] = bl4(rby, (unsigned)((cb * H + y0_ + (o >> 1)) * W + x0_ + (o & 1)) * 64u + (unsigned)kq * 16u, 0u);
-      }
       f32x4 Y[2][2] = {{zero4, zero4}, {zero4, zero4}};
       SIFSR_DIAG_SKIP_MATRIX_WORK(a.B < 0) {   // (diag.h: nothing in the shipped build)
       f32x2 dl[4][4], dh[4][4];
@@ -301,8 +307,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
           v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
         }
         bs4(rd, pixo, 0u, make_float4(v[0], v[1], v[2], v[3]));
-        if (bn_stats) {   // dz = g_in * [y_below * scale + shift > 0]; sum dz, sum dz * y_below
-          const float yy4[4] = {yq[o].x, yq[o].y, yq[o].z, yq[o].w};
+        if (bn_stats) {   // dz = g_in * [y_below * scale + shift > 0]; sum dz, sum dz * y_below.  y_below = the staged x tile (raw) in LDS:
+          // channel 4 kq + r lives in plane kq + 4 r, pixel (row + 1, column + 1) of the halo.  (Round 3: these were four global
+          // loads per lane requested before the MFMAs -- under this kernel's memory load they came back after the contraction
+          // and the input-gradient waves spent 2/3 of their phase waiting for them, tools/clock_probe16.py)
+          const float* yp_ = xp[buf] + kq * XPS + (g0 + 2 * pyl + oy + 1) * XPW + 2 * pxp + ox + 1;
+          const float yy4[4] = {yp_[0], yp_[4 * XPS], yp_[8 * XPS], yp_[12 * XPS]};
           const float scv[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, shv[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -344,6 +354,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
           f32x2 wl[4], wh[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) { wl[u] = *reinterpret_cast<const f32x2*>(q + u * XPW); wh[u] = *reinterpret_cast<const f32x2*>(q + u * XPW + 2); }
+          if (!xraw) {
+            const f32x2 z2 = {0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              wl[u] = __builtin_elementwise_max(__builtin_elementwise_fma(wl[u], xs2, xb2), z2);
+              wh[u] = __builtin_elementwise_max(__builtin_elementwise_fma(wh[u], xs2, xb2), z2);
+            }
+          }
           // rows: [d0 - d2, d1 + d2, d2 - d1, d3 - d1] on both pixel pairs
           const f32x2 rl[4] = {pk_sub(wl[0], wl[2]), pk_add(wl[1], wl[2]), pk_sub(wl[2], wl[1]), pk_sub(wl[3], wl[1])};
           const f32x2 rh[4] = {pk_sub(wh[0], wh[2]), pk_add(wh[1], wh[2]), pk_sub(wh[2], wh[1]), pk_sub(wh[3], wh[1])};
@@ -423,6 +441,8 @@ int launch_conv3x3_bwd16(const Bwd16Args& a, hipStream_t s) {
   if (!a.x || !a.g || !a.wpack_wino || !a.gin || !a.slabs) return SIFSR_ERR_ARG;
   if ((a.y != nullptr) != (a.coef != nullptr) || (a.x_scale != nullptr) != (a.x_shift != nullptr)) return SIFSR_ERR_ARG;
   if (a.stat_partials != nullptr && (!a.bn_y || !a.bn_scale || !a.bn_shift)) return SIFSR_ERR_ARG;
+  // the BatchNorm sums are taken from the staged input tile: the layer below IS the layer whose raw output is the input
+  if (a.stat_partials != nullptr && (a.bn_y != a.x || a.bn_scale != a.x_scale || a.bn_shift != a.x_shift)) return SIFSR_ERR_ARG;
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
   auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
   const int tx_ = a.W / 16, ty_ = a.H / 16, ntiles = a.B * tx_ * ty_;

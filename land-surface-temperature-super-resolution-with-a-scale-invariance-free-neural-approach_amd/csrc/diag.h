@@ -5,7 +5,8 @@
 //   -DSIFSR_DIAG_NOMFMA    the conv kernels without their window reads, transforms and MFMAs (results are zeros): what a kernel's
 //                          data movement alone costs (tools/nomfma_sweep.sh, profiles/r02_nomfma_sweep.txt)
 //   -DSIFSR_DIAG_CLOCK     shader-clock / 100 MHz stamps around the item loop of conv3x3_wino8_kernel, read back through
-//                          sifsr_debug_timers() (tools/clock_probe.py: the in-kernel clock under load)
+//                          sifsr_debug_timers() (tools/clock_probe.py: the in-kernel clock under load), and per-phase / per-role
+//                          clock sums of conv3x3_bwd16_kernel through sifsr_debug_timers16() (tools/clock_probe16.py)
 //   -DSIFSR_PK_MODE=0..3   form of the packed add / subtract of the Winograd transforms (common.h; 0 ships)
 #pragma once
 
@@ -29,9 +30,32 @@
     if (reset) { unsigned long long z[4] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sifsr_clk), z, 32) != hipSuccess) return 2; } \
     return 0;                                                                                                            \
   }
+// conv3x3_bwd16_kernel: shader-clock ticks per phase and wave role, summed over workgroups (wave 0 of each role reports):
+//   [0..3] input-gradient role: staging (incl. the wait for the tile's loads), contraction (+ epilogue), barrier wait, tile count;
+//   [4..7] the same for the weight-gradient role;  [8], [9]: of the staging time, the wait for the prefetched loads per role
+#define SIFSR_DIAG_CLOCK16_DECL                                                                                             \
+  __device__ unsigned long long sifsr_clk16[10];                                                                          \
+  extern "C" __attribute__((visibility("default"))) int sifsr_debug_timers16(unsigned long long* out10, int reset) {      \
+    if (hipMemcpyFromSymbol(out10, HIP_SYMBOL(sifsr_clk16), 80) != hipSuccess) return 1;                                  \
+    if (reset) { unsigned long long z[10] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sifsr_clk16), z, 80) != hipSuccess) return 2; } \
+    return 0;                                                                                                             \
+  }
+#define SIFSR_DIAG_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define SIFSR_DIAG_ACC16(i, d) do { if (lane == 0 && wave == 0) atomicAdd(&sifsr_clk16[(i)], (unsigned long long)(d)); } while (0)
+#define SIFSR_DIAG_WAIT_LOADS(var)                                   \
+  unsigned long long var = 0;                                        \
+  {                                                                  \
+    const unsigned long long w0__ = __builtin_amdgcn_s_memtime();    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+    var = __builtin_amdgcn_s_memtime() - w0__;                       \
+  }
 #else
 #define SIFSR_DIAG_CLOCK_DECL
 #define SIFSR_DIAG_CLOCK_BEGIN
 #define SIFSR_DIAG_CLOCK_END(tid)
 #define SIFSR_DIAG_CLOCK_READER
+#define SIFSR_DIAG_CLOCK16_DECL
+#define SIFSR_DIAG_T(var)
+#define SIFSR_DIAG_ACC16(i, d)
+#define SIFSR_DIAG_WAIT_LOADS(var)
 #endif
