@@ -147,7 +147,10 @@ SIFSR_API int sifsr_conv3x3_wgrad_wino(const float* src0, int C0, const float* s
  *   bn_partials != NULL: gin is the gradient w.r.t. relu(bn(bn_y)) of the layer below -- bn_y, bn_scale, bn_shift must BE x, x_scale,
  *   x_shift (the layer below is the layer whose raw output is this layer's input) -- and its BatchNorm-backward sums are emitted as sifsr_conv3x3_bwd16_stat_rows() rows of [16][2]
  *   (sum dz, sum dz*y per channel; dz = gin*[bn_y*scale+shift > 0]); add the rows up.  Not together with addend.
- *   scratch: sifsr_conv3x3_bwd16_scratch_floats() floats (weight-gradient slabs + their float64 sum). */
+ *   scratch: sifsr_conv3x3_bwd16_scratch_floats() floats (weight-gradient slabs + their float64 sum).
+ *   After sifsr_set_op_storage_bf16(1) the activation tensors (x, g, y, border, gin, addend, bn_y) are NHWC bf16 -- what the model's
+ *   bf16 mode runs for these layers: half the bytes, fp32 arithmetic (fp32 MFMAs in the Winograd domain; the border fold rounds
+ *   its operands to bf16 as the bf16 input-gradient kernel does). */
 SIFSR_API int sifsr_conv3x3_bwd16_stat_rows(int B, int H, int W);
 SIFSR_API size_t sifsr_conv3x3_bwd16_scratch_floats(int B, int H, int W);
 SIFSR_API int sifsr_conv3x3_bwd16(const float* x, const float* x_scale, const float* x_shift, const float* g, const float* y,

@@ -288,9 +288,11 @@ int sifsr_conv3x3_bwd16(const float* x, const float* x_scale, const float* x_shi
   a.wpack_wino = wwd; a.gin = gin; a.addend = addend;
   if (bn_partials != nullptr) { a.bn_y = bn_y; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.stat_partials = bn_partials; }
   a.slabs = scratch; a.B = B; a.H = H; a.W = W;
+  a.half = sifsr_half_storage() ? 1 : 0;      // sifsr_set_op_storage_bf16(1): x, g, y, border, gin, addend, bn_y are bf16 tensors
   int rc = launch_conv3x3_bwd16(a, S(stream));
   if (rc) return rc;
-  rc = launch_dgrad_border_fix(y ? border : g, 16, wdgrad, 16, gin, 16, 16, gin, 16, B, H, W, S(stream), 0,
+  // (bf16 storage: the fold reads / updates bf16 tensors but keeps fp32 products, like the main kernel -- flag 2)
+  rc = launch_dgrad_border_fix(y ? border : g, 16, wdgrad, 16, gin, 16, 16, gin, 16, B, H, W, S(stream), a.half,
                                bn_partials ? bn_y : nullptr, bn_partials ? bn_scale : nullptr, bn_partials ? bn_shift : nullptr,
                                bn_partials ? bn_partials + (size_t)grid * 32 : nullptr);
   if (rc) return rc;

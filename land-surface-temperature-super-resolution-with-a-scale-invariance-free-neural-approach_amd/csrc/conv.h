@@ -110,6 +110,8 @@ struct Bwd16Args {
   float* slabs;                    // out: conv3x3_bwd16_grid() weight-gradient slabs of 16 * 256 floats (Winograd domain,
                                    //   the layout of conv_wgrad_wino.hip; reduce with launch_wgrad_wino_finish, nblk = grid)
   int B, H, W;
+  int half = 0;                    // 1: the activation tensors above are stored as bf16 (the bf16 compute mode; the arithmetic stays
+                                   //    fp32 -- fp32 MFMAs in the Winograd domain: these layers are HBM-bound, what counts is the bytes)
 };
 bool conv3x3_bwd16_applies(int B, int H, int W);
 int conv3x3_bwd16_grid(int B, int H, int W);           // workgroups launched = stat_partials rows = slabs

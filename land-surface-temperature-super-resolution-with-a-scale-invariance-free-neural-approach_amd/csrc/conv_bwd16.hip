@@ -48,9 +48,25 @@ static __device__ __forceinline__ void bs4(__amdgpu_buffer_rsrc_t r, unsigned vo
   u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
   __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, (int)soff, 0);
 }
+// activation access: byte offsets of the fp32 layout; HS (bf16 storage, the bf16 compute mode -- common.h) halves them
+template <bool HS> static __device__ __forceinline__ float4 al4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if constexpr (HS) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2b;
+    const u32x2b v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(voff >> 1), (int)(soff >> 1), 0);
+    return unpack_bf16x4(make_uint2(v.x, v.y));
+  } else return bl4(r, voff, soff);
+}
+template <bool HS> static __device__ __forceinline__ void as4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 v) {
+  if constexpr (HS) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2b;
+    const uint2 p = pack_bf16x4(v);
+    u32x2b u; u.x = p.x; u.y = p.y;
+    __builtin_amdgcn_raw_buffer_store_b64(u, r, (int)(voff >> 1), (int)(soff >> 1), 0);
+  } else bs4(r, voff, soff, v);
+}
 static __device__ __forceinline__ int xslot(int i) { return (i >> 2) + 4 * (i & 3); }
 
-template <bool DYF>
+template <bool DYF, bool HS>   // HS: every activation tensor (x, g, y, gin, addend, the border scratch) is stored as bf16
 __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a, const int ntiles, const int lgx, const int lgy) {
   __shared__ float4 dyq[2][DYQ_F4];                       // dL/dy halo, [cout quad][pixel (even | odd columns)][4]
   __shared__ __align__(16) float dyp[2][DYP_F + 16];      // dL/dy core, channel planes
@@ -79,10 +95,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
 
   for (int i = tid; i < 16 * 64; i += 512) wlds[i] = ld4(a.wpack_wino + 4 * (size_t)i);
 
-  const __amdgpu_buffer_rsrc_t rg = mk_rsrc(a.g, npix * 64u);
-  const __amdgpu_buffer_rsrc_t ry = mk_rsrc(DYF ? a.y : a.g, npix * 64u);
-  const __amdgpu_buffer_rsrc_t rx = mk_rsrc(a.x, npix * 64u);
-  const __amdgpu_buffer_rsrc_t rbd = mk_rsrc(DYF && a.dy_border ? a.dy_border : const_cast<float*>(a.g), npix * 64u);
+  constexpr unsigned PXB = HS ? 32u : 64u;                // bytes per pixel (16 channels)
+  const __amdgpu_buffer_rsrc_t rg = mk_rsrc(a.g, npix * PXB);
+  const __amdgpu_buffer_rsrc_t ry = mk_rsrc(DYF ? a.y : a.g, npix * PXB);
+  const __amdgpu_buffer_rsrc_t rx = mk_rsrc(a.x, npix * PXB);
+  const __amdgpu_buffer_rsrc_t rbd = mk_rsrc(DYF && a.dy_border ? a.dy_border : const_cast<float*>(a.g), npix * PXB);
 
   // ---- staging map: thread -> (channel quad cg, halo pixels pslot + 128 it, it < 3)
   const int cg = tid & 3, pslot = tid >> 2;
@@ -115,9 +132,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
       const unsigned soff = (unsigned)((st_b * H + y0) * W + x0) * 64u;
 #pragma unroll
       for (int it = 0; it < 3; ++it) {
-        pg[it] = bl4(rg, rel[it], soff);
-        if (DYF) py[it] = bl4(ry, rel[it], soff);
-        px_[it] = bl4(rx, rel[it], soff);
+        pg[it] = al4<HS>(rg, rel[it], soff);
+        if (DYF) py[it] = al4<HS>(ry, rel[it], soff);
+        px_[it] = al4<HS>(rx, rel[it], soff);
       }
     } else {
 #pragma unroll
@@ -125,9 +142,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
         const int gy = y0 + spy[it], gx = x0 + spx[it];
         const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
         const unsigned pc = (unsigned)((st_b * H + clampi(gy, 0, H - 1)) * W + clampi(gx, 0, W - 1)) * 64u + (unsigned)cg * 16u;
-        pg[it] = bl4(rg, inside ? pc : OOB, 0u);          // zero padding of dL/dy
-        if (DYF) py[it] = bl4(ry, inside ? pc : OOB, 0u);
-        px_[it] = bl4(rx, pc, 0u);                        // replicate padding of the forward input
+        pg[it] = al4<HS>(rg, inside ? pc : OOB, 0u);          // zero padding of dL/dy
+        if (DYF) py[it] = al4<HS>(ry, inside ? pc : OOB, 0u);
+        px_[it] = al4<HS>(rx, pc, 0u);                        // replicate padding of the forward input
       }
     }
   };
@@ -149,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
           if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);   // bn_bwd4 of the zeros that were loaded is not 0
           const bool edge = gy == 0 || gy == H - 1 || gx == 0 || gx == W - 1;
           if (a.dy_border != nullptr && inside && lp[it] >= 0 && edge)   // dL/dy on the image border, for the border-fold kernel
-            bs4(rbd, (unsigned)((st_b * H + gy) * W + gx) * 64u + (unsigned)cg * 16u, 0u, v);
+            as4<HS>(rbd, (unsigned)((st_b * H + gy) * W + gx) * 64u + (unsigned)cg * 16u, 0u, v);
         }
       }
       Q[lq[it]] = v;
@@ -170,8 +187,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
   const int pxp = lane & 7, pyl = (lane >> 3) & 1;
   const int g0 = wave * 4;
   const int lbase = kq * WPLANE + (g0 + 2 * pyl) * WPITCH + pxp;
-  const __amdgpu_buffer_rsrc_t rd = mk_rsrc(a.gin, npix * 64u);
-  const __amdgpu_buffer_rsrc_t rad = mk_rsrc(a.addend ? a.addend : a.gin, npix * 64u);
+  const __amdgpu_buffer_rsrc_t rd = mk_rsrc(a.gin, npix * PXB);
+  const __amdgpu_buffer_rsrc_t rad = mk_rsrc(a.addend ? a.addend : a.gin, npix * PXB);
   const bool bn_stats = a.bn_y != nullptr;
   float4 bsc = make_float4(0.f, 0.f, 0.f, 0.f), bsh = bsc;
   if (bn_stats) { bsc = ld4(a.bn_scale + 4 * kq); bsh = ld4(a.bn_shift + 4 * kq); }
@@ -303,10 +320,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
         f32x4 v = Y[oy][ox];
         const unsigned pixo = (unsigned)((cb * H + yy) * W + xx) * 64u + (unsigned)kq * 16u;
         if (a.addend != nullptr) {
-          const float4 ad = bl4(rad, pixo, 0u);
+          const float4 ad = al4<HS>(rad, pixo, 0u);
           v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
         }
-        bs4(rd, pixo, 0u, make_float4(v[0], v[1], v[2], v[3]));
+        if (HS) {   // the BatchNorm sums below are those of the STORED (bf16-rounded) gradient
+          const float4 vr = round_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
+          v = (f32x4){vr.x, vr.y, vr.z, vr.w};
+        }
+        as4<HS>(rd, pixo, 0u, make_float4(v[0], v[1], v[2], v[3]));
         if (bn_stats) {   // dz = g_in * [y_below * scale + shift > 0]; sum dz, sum dz * y_below.  y_below = the staged x tile (raw) in LDS:
           // channel 4 kq + r lives in plane kq + 4 r, pixel (row + 1, column + 1) of the halo.  (Round 3: these were four global
           // loads per lane requested before the MFMAs -- under this kernel's memory load they came back after the contraction
@@ -448,8 +469,13 @@ int launch_conv3x3_bwd16(const Bwd16Args& a, hipStream_t s) {
   const int tx_ = a.W / 16, ty_ = a.H / 16, ntiles = a.B * tx_ * ty_;
   const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
   const dim3 grid(conv3x3_bwd16_grid(a.B, a.H, a.W)), block(512);
-  if (a.y != nullptr) hipLaunchKernelGGL((conv3x3_bwd16_kernel<true>), grid, block, 0, s, a, ntiles, lgx, lgy);
-  else hipLaunchKernelGGL((conv3x3_bwd16_kernel<false>), grid, block, 0, s, a, ntiles, lgx, lgy);
+  if (a.half) {
+    if (a.y != nullptr) hipLaunchKernelGGL((conv3x3_bwd16_kernel<true, true>), grid, block, 0, s, a, ntiles, lgx, lgy);
+    else hipLaunchKernelGGL((conv3x3_bwd16_kernel<false, true>), grid, block, 0, s, a, ntiles, lgx, lgy);
+  } else {
+    if (a.y != nullptr) hipLaunchKernelGGL((conv3x3_bwd16_kernel<true, false>), grid, block, 0, s, a, ntiles, lgx, lgy);
+    else hipLaunchKernelGGL((conv3x3_bwd16_kernel<false, false>), grid, block, 0, s, a, ntiles, lgx, lgy);
+  }
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

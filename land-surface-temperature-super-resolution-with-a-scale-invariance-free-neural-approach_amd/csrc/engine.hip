@@ -473,7 +473,11 @@ int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin
   *applied = false;
   if (stat_rows) *stat_rows = 0;
   const int lh = c.lvH(L.level), lw = c.lvW(L.level);
-  if (L.cin != 16 || L.cout != 16 || c.bf16 != 0 || c.xjobs == nullptr || !wgrad_wino_policy(16, 16) || s0.C != 16 || s0.coff != 0 ||
+  // bf16 mode: the fused kernel exists for bf16 STORAGE too (fp32 Winograd arithmetic on widened values), but there it LOSES:
+  // 14,450 against 15,900 patches/s on the bf16 step -- with half the bytes its fp32 matrix + transform work is the bottleneck,
+  // while the separate bf16 kernels contract with 16x cheaper MFMAs.  SIFSR_BF16_BWD16=1 selects it for A/B.
+  static const int bf16_fused = getenv("SIFSR_BF16_BWD16") ? atoi(getenv("SIFSR_BF16_BWD16")) : 0;
+  if (L.cin != 16 || L.cout != 16 || (c.bf16 != 0 && !bf16_fused) || c.xjobs == nullptr || !wgrad_wino_policy(16, 16) || s0.C != 16 || s0.coff != 0 ||
       !conv3x3_bwd16_applies(c.B, lh, lw))
     return SIFSR_OK;
   const bool fuse = bn_layer >= 0 && addend == nullptr && c.nt.L[bn_layer].cout == 16 && c.nt.L[bn_layer].level == L.level;
@@ -491,12 +495,13 @@ int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin
   }
   a.slabs = c.f(c.lay.slab_l[l]);
   a.B = c.B; a.H = lh; a.W = lw;
+  a.half = c.bf16;
   {
     ProfScope ps(l, 2, c.s);     // one launch = both passes of the layer: timed as its input-gradient selection
     SIFSR_TRY(launch_conv3x3_bwd16(a, c.s));
   }
   const float* wdg_f32 = c.f(c.lay.wdg) + 4 * (size_t)L.wpack_off;
-  SIFSR_TRY(launch_dgrad_border_fix(dy_stored ? dy : a.dy_border, 16, wdg_f32, 16, gin, 16, 16, gin, 16, c.B, lh, lw, c.s, 0,
+  SIFSR_TRY(launch_dgrad_border_fix(dy_stored ? dy : a.dy_border, 16, wdg_f32, 16, gin, 16, 16, gin, 16, c.B, lh, lw, c.s, c.bf16,
                                     fuse ? a.bn_y : nullptr, fuse ? a.bn_scale : nullptr, fuse ? a.bn_shift : nullptr,
                                     fuse ? c.f(c.lay.bpart) : nullptr));
   WgradReduceJob& j = c.xjobs[(*c.nxjobs)++];

@@ -313,3 +313,73 @@ def test_bf16_other_sizes_and_determinism(sifsr):
     g32 = m.flat_grad()
     assert rel_err(sr.detach(), sr32.detach()) < 8e-2
     assert float((grads[0] - g32).norm() / g32.norm()) < 0.5      # (small random-init patches: ~0.25)
+
+
+@pytest.mark.parametrize("case", [(32, 48, 2, True, True), (64, 64, 3, True, False), (128, 128, 4, False, True)])
+def test_bf16_storage_fused_backward_of_16_channel_layers(L, case):
+    """sifsr_conv3x3_bwd16 on bf16 tensors (available to the bf16 mode, SIFSR_BF16_BWD16=1; not its default -- the separate bf16-MFMA
+    kernels are faster once the bytes are halved): input gradient (bf16 out,
+    incl. the border fold) and weight gradient (fp32 out) of z = relu(bn(conv(a))), a = relu(x*xs + xsh), against float64
+    autograd on the values the bf16 tensors hold; the BatchNorm sums of the layer below are those of the stored gradient."""
+    H, W, B, dyf, with_stats = case
+    C = 16
+    rs = np.random.RandomState(sum(case[:3]))
+    x = rb(torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32)))
+    xs = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)); xsh = torch.from_numpy((0.3 * rs.standard_normal(C)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((C, C, 3, 3)) * (2.0 / (9 * C)) ** 0.5).astype(np.float32))
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)); beta = torch.from_numpy((0.5 * rs.standard_normal(C)).astype(np.float32))
+    g = rb(torch.from_numpy(rs.standard_normal((B, C, H, W)).astype(np.float32)))
+    conv = lambda a, b: F.conv2d(F.pad(a, (1, 1, 1, 1), mode="replicate"), b)
+    a64 = F.relu(x.double() * xs.double().view(1, -1, 1, 1) + xsh.double().view(1, -1, 1, 1)).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    # the layer's own raw output as the bf16 tensor the forward would have stored, and its batch statistics
+    y = rb(conv(a64.detach().float(), w))
+    mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    if dyf:
+        # dL/dy from (g, y) with the coefficients the statistics pass leaves (float64 reference of the same formula)
+        z = y.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+        dz = torch.where(z > 0, g.double(), torch.zeros_like(z))
+        n = B * H * W
+        xhat = (y.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
+        dbeta, dgamma = dz.sum((0, 2, 3)), (dz * xhat).sum((0, 2, 3))
+        dy64 = scale.double().view(1, -1, 1, 1) * (dz - dbeta.view(1, -1, 1, 1) / n - xhat * dgamma.view(1, -1, 1, 1) / n)
+    else:
+        dy64 = g.double()
+    ga_ref, gw_ref = torch.autograd.grad(conv(a64, w64), [a64, w64], dy64)
+    S_ = S()
+    wf = torch.empty(9 * C * C, device="cuda"); wd = torch.empty(4 * 9 * C * C, device="cuda")
+    L.call("sifsr_pack_conv_weights", w.cuda(), C, C, wf, wd, S_)
+    wwf = torch.empty(16 * C * C, device="cuda"); wwd = torch.empty(16 * C * C, device="cuda")
+    L.call("sifsr_pack_conv_weights_wino", w.cuda(), C, C, wwf, wwd, S_)
+    dx, dg, dyy = nhwc_bf(x), nhwc_bf(g), nhwc_bf(y)
+    coef_f = None
+    if dyf:
+        partials = torch.empty(1024 * C * 2, device="cuda")
+        dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        coef = torch.empty(3 * C, dtype=torch.float64, device="cuda"); coef_f = torch.empty(4 * C, device="cuda")
+        L.call("sifsr_bn_relu_bwd_coef", dg, dyy, scale.cuda(), shift.cuda(), mean.cuda(), invstd.cuda(), beta.cuda(), C, B * H * W,
+               partials, 4, dgam, dbet, coef, coef_f, None, H, W, S_)
+    rows = L.call("sifsr_conv3x3_bwd16_stat_rows", B, H, W)
+    scratch = torch.empty(L.call("sifsr_conv3x3_bwd16_scratch_floats", B, H, W), device="cuda")
+    gin = torch.empty(B, H, W, C, dtype=BF, device="cuda"); dw = torch.empty(C, C, 3, 3, device="cuda")
+    border = torch.zeros(B, H, W, C, dtype=BF, device="cuda")
+    bnp = torch.empty(rows, C, 2, device="cuda") if with_stats else None
+    dxs, dxsh = xs.cuda(), xsh.cuda()                          # (the fused sums require bn_y / scale / shift to BE x / x_scale / x_shift)
+    L.call("sifsr_conv3x3_bwd16", dx, dxs, dxsh, dg if dyf else nhwc_bf(dy64.float()), dyy if dyf else None, coef_f,
+           border if dyf else None, wd, wwd, gin, None, dx if with_stats else None, dxs if with_stats else None,
+           dxsh if with_stats else None, bnp, scratch, dw, B, H, W, S_)
+    torch.cuda.synchronize()
+    dy_used = dy64 if dyf else rb(dy64.float()).double()      # stored dL/dy is itself a bf16 tensor
+    ga_ref2, gw_ref2 = torch.autograd.grad(conv(a64, w64), [a64, w64], dy_used) if not dyf else (ga_ref, gw_ref)
+    got = from_nhwc(gin).double()
+    # the border fold contracts bf16-rounded operands (as the bf16 input-gradient kernel): one more rounding on the image border
+    assert float((got - ga_ref2).abs().max()) <= 1.2e-2 * float(ga_ref2.abs().max())
+    assert float((got - ga_ref2).abs().mean()) <= 2.5e-3 * float(ga_ref2.abs().mean())
+    assert rel_err(dw.cpu(), gw_ref2) < (2e-3 if dyf else 1e-5)     # dyf: dL/dy is formed from bf16 (g, y) with fp32 coefficients
+    if with_stats:
+        zpos = (x.double() * xs.double().view(1, -1, 1, 1) + xsh.double().view(1, -1, 1, 1)) > 0
+        dzs = torch.where(zpos, got, torch.zeros_like(got))
+        ref = torch.stack((dzs.sum((0, 2, 3)), (dzs * x.double()).sum((0, 2, 3))), 1)
+        assert rel_err(bnp.double().sum(0).cpu(), ref) < 2e-3          # (border fold deltas are summed unrounded)
