@@ -157,6 +157,16 @@ SIFSR_API int sifsr_conv3x3_bwd16(const float* x, const float* x_scale, const fl
                                   const float* coef_f, float* border, const float* wdgrad, const float* wwd, float* gin,
                                   const float* addend, const float* bn_y, const float* bn_scale, const float* bn_shift,
                                   float* bn_partials, float* scratch, float* dw, int B, int H, int W, void* stream);
+/* The same for the LAST 16 -> 16 layer, ub3.convbloc.bloc.3, whose output feeds outlay (Conv2d(16, 1, 3, padding_mode="replicate"),
+ * model.py:605): the upstream gradient g = outlay^T(dsr) is never stored -- each staged pixel recomputes it from a 20x20 tile of
+ * dsr = d loss / d sr ([B][H][W] fp32, in every storage mode) and w_out ([1][16][3][3]), replicate-padding adjoint included; the rest
+ * (y, coef_f, border, gin, dw, the BatchNorm sums of the layer below) as sifsr_conv3x3_bwd16 with y != NULL and no addend.
+ * Replaces tail_bwd_apply's write + re-read of dL/dy (2 tensor passes of 16 x 256^2 x batch). */
+SIFSR_API int sifsr_conv3x3_bwd16_tail(const float* x, const float* x_scale, const float* x_shift, const float* dsr,
+                                       const float* w_out, const float* y, const float* coef_f, float* border,
+                                       const float* wdgrad, const float* wwd, float* gin, const float* bn_y,
+                                       const float* bn_scale, const float* bn_shift, float* bn_partials, float* scratch,
+                                       float* dw, int B, int H, int W, void* stream);
 /* bf16 form of the weight gradient (BASELINE.json config 5): src* and dy are NHWC bf16 tensors; the staged x and dy are
  * rounded to bf16 when read from LDS and contracted 16 pixels at a time with v_mfma_f32_16x16x16_bf16; fp32 accumulation,
  * slabs and dw. */

@@ -10,7 +10,7 @@ static ConvSrc mk_src(const float* p, int C, const float* sc, const float* sh) {
   return s;
 }
 
-int sifsr_abi_version(void) { return 3; }   // 2: Winograd-domain entry points, fused BatchNorm-backward forms (round 2); 3: sifsr_conv3x3_bwd16, split-bf16 entry points removed (round 3)
+int sifsr_abi_version(void) { return 3; }   // 2: Winograd-domain entry points, fused BatchNorm-backward forms (round 2); 3: sifsr_conv3x3_bwd16(_tail), split-bf16 entry points removed (round 3)
 int sifsr_num_params(void) { return sifsr_net().total_params; }
 int sifsr_num_running(void) { return sifsr_net().total_running; }
 int sifsr_layer_table(int* out, int capacity_rows) {
@@ -274,6 +274,22 @@ int sifsr_conv3x3_bwd16_stat_rows(int B, int H, int W) {
 size_t sifsr_conv3x3_bwd16_scratch_floats(int B, int H, int W) {
   return conv3x3_bwd16_applies(B, H, W) ? ((size_t)conv3x3_bwd16_grid(B, H, W) + 2) * 16 * 256 : 0;
 }
+static int bwd16_op(Bwd16Args a, const float* dy_edge, const float* wdgrad, float* bn_partials, float* scratch, float* dw, void* stream) {
+  const int B = a.B, H = a.H, W = a.W;
+  const int grid = conv3x3_bwd16_grid(B, H, W);
+  a.slabs = scratch;
+  a.half = sifsr_half_storage() ? 1 : 0;      // sifsr_set_op_storage_bf16(1): x, g, y, border, gin, addend, bn_y are bf16 tensors
+  int rc = launch_conv3x3_bwd16(a, S(stream));
+  if (rc) return rc;
+  // (bf16 storage: the fold reads / updates bf16 tensors but keeps fp32 products, like the main kernel -- flag 2)
+  rc = launch_dgrad_border_fix(dy_edge, 16, wdgrad, 16, a.gin, 16, 16, a.gin, 16, B, H, W, S(stream), a.half,
+                               bn_partials ? a.bn_y : nullptr, bn_partials ? a.bn_scale : nullptr, bn_partials ? a.bn_shift : nullptr,
+                               bn_partials ? bn_partials + (size_t)grid * 32 : nullptr);
+  if (rc) return rc;
+  WgradReduceJob j;
+  j.slab_off = 0; j.nblk = grid; j.cin = 16; j.cout = 16; j.nbi_chunk = 1; j.w_off = 0;
+  return launch_wgrad_wino_finish(scratch, &j, 1, reinterpret_cast<double*>(scratch + (size_t)grid * 16 * 256), dw, S(stream));
+}
 int sifsr_conv3x3_bwd16(const float* x, const float* x_scale, const float* x_shift, const float* g, const float* y,
                         const float* coef_f, float* border, const float* wdgrad, const float* wwd, float* gin,
                         const float* addend, const float* bn_y, const float* bn_scale, const float* bn_shift,
@@ -282,23 +298,28 @@ int sifsr_conv3x3_bwd16(const float* x, const float* x_scale, const float* x_shi
   if (!x || !g || !wdgrad || !wwd || !gin || !scratch || !dw) return SIFSR_ERR_ARG;
   if ((y != nullptr) != (coef_f != nullptr) || (y != nullptr && !border)) return SIFSR_ERR_ARG;
   if (bn_partials != nullptr && (!bn_y || !bn_scale || !bn_shift || addend != nullptr)) return SIFSR_ERR_ARG;
-  const int grid = conv3x3_bwd16_grid(B, H, W);
   Bwd16Args a;
   a.x = x; a.x_scale = x_scale; a.x_shift = x_shift; a.g = g; a.y = y; a.coef = coef_f; a.dy_border = y ? border : nullptr;
   a.wpack_wino = wwd; a.gin = gin; a.addend = addend;
   if (bn_partials != nullptr) { a.bn_y = bn_y; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.stat_partials = bn_partials; }
-  a.slabs = scratch; a.B = B; a.H = H; a.W = W;
-  a.half = sifsr_half_storage() ? 1 : 0;      // sifsr_set_op_storage_bf16(1): x, g, y, border, gin, addend, bn_y are bf16 tensors
-  int rc = launch_conv3x3_bwd16(a, S(stream));
-  if (rc) return rc;
-  // (bf16 storage: the fold reads / updates bf16 tensors but keeps fp32 products, like the main kernel -- flag 2)
-  rc = launch_dgrad_border_fix(y ? border : g, 16, wdgrad, 16, gin, 16, 16, gin, 16, B, H, W, S(stream), a.half,
-                               bn_partials ? bn_y : nullptr, bn_partials ? bn_scale : nullptr, bn_partials ? bn_shift : nullptr,
-                               bn_partials ? bn_partials + (size_t)grid * 32 : nullptr);
-  if (rc) return rc;
-  WgradReduceJob j;
-  j.slab_off = 0; j.nblk = grid; j.cin = 16; j.cout = 16; j.nbi_chunk = 1; j.w_off = 0;
-  return launch_wgrad_wino_finish(scratch, &j, 1, reinterpret_cast<double*>(scratch + (size_t)grid * 16 * 256), dw, S(stream));
+  a.B = B; a.H = H; a.W = W;
+  return bwd16_op(a, y ? border : g, wdgrad, bn_partials, scratch, dw, stream);
+}
+// ... of the LAST 16 -> 16 layer (ub3.convbloc.bloc.3): the upstream gradient g is the input gradient of outlay (Conv2d 16 -> 1,
+// replicate padding, model.py:605) and is recomputed while staging from dsr = d loss / d sr [B][H][W] (fp32) and w_out [1][16][3][3]
+int sifsr_conv3x3_bwd16_tail(const float* x, const float* x_scale, const float* x_shift, const float* dsr, const float* w_out,
+                             const float* y, const float* coef_f, float* border, const float* wdgrad, const float* wwd, float* gin,
+                             const float* bn_y, const float* bn_scale, const float* bn_shift, float* bn_partials, float* scratch,
+                             float* dw, int B, int H, int W, void* stream) {
+  if (!conv3x3_bwd16_applies(B, H, W)) return SIFSR_ERR_SHAPE;
+  if (!x || !dsr || !w_out || !y || !coef_f || !border || !wdgrad || !wwd || !gin || !scratch || !dw) return SIFSR_ERR_ARG;
+  if (bn_partials != nullptr && (!bn_y || !bn_scale || !bn_shift)) return SIFSR_ERR_ARG;
+  Bwd16Args a;
+  a.x = x; a.x_scale = x_scale; a.x_shift = x_shift; a.tail_dsr = dsr; a.tail_w = w_out; a.y = y; a.coef = coef_f; a.dy_border = border;
+  a.wpack_wino = wwd; a.gin = gin;
+  if (bn_partials != nullptr) { a.bn_y = bn_y; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.stat_partials = bn_partials; }
+  a.B = B; a.H = H; a.W = W;
+  return bwd16_op(a, border, wdgrad, bn_partials, scratch, dw, stream);
 }
 
 // bf16-operand form (config 5): x and dy rounded to bf16 when read from LDS, fp32 accumulation

@@ -96,7 +96,9 @@ struct Bwd16Args {
   const float* x;                  // the layer's forward input: a raw conv output (x_scale / x_shift = the folded BatchNorm of the
   const float* x_scale = nullptr;  //   layer below, relu(x * scale + shift) applied while staging) or, with nullptr, a stored tensor
   const float* x_shift = nullptr;
-  const float* g;                  // dL/d relu(bn(y)) of this layer -- or dL/dy itself when y == nullptr
+  const float* g = nullptr;        // dL/d relu(bn(y)) of this layer -- or dL/dy itself when y == nullptr
+  const float* tail_dsr = nullptr; // instead of g ("tail", ub3.convbloc.bloc.3): g is the input gradient of outlay (Conv2d 16 -> 1, replicate
+  const float* tail_w = nullptr;   //   padding), recomputed while staging from d loss / d sr [B][H][W] (fp32) and the outlay weight [1][16][3][3]
   const float* y = nullptr;        // this layer's raw conv output: dL/dy is formed while staging (bn_bwd4) ...
   const float* coef = nullptr;     // ... from [sc | sh | k1 | k0], 16 floats each (bn_bwd_finalize*)
   float* dy_border = nullptr;      // with y: dL/dy of the image-border pixels goes here (NHWC indexing) for the border-fold kernel

@@ -66,13 +66,21 @@ template <bool HS> static __device__ __forceinline__ void as4(__amdgpu_buffer_rs
 }
 static __device__ __forceinline__ int xslot(int i) { return (i >> 2) + 4 * (i & 3); }
 
-template <bool DYF, bool HS>   // HS: every activation tensor (x, g, y, gin, addend, the border scratch) is stored as bf16
+// DYM: where dL/dy comes from.  0: stored (a.g).  1: formed while staging from (g, y) by the BatchNorm+ReLU backward (bn_bwd4).
+// 2 ("tail", ub3.convbloc.bloc.3): as 1, but g itself -- the input gradient of outlay (Conv2d 16 -> 1, model.py:605) -- is
+// recomputed per staged pixel from a 20x20 tile of d loss / d sr (9 LDS reads, 36 FMAs per pixel and channel quad) instead of
+// being written to and read back from HBM by tail_bwd_apply_kernel (fused_edges.hip).
+// HS: every activation tensor (x, g, y, gin, addend, the border scratch) is stored as bf16
+template <int DYM, bool HS>
 __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a, const int ntiles, const int lgx, const int lgy) {
+  constexpr bool DYF = DYM != 0, TAIL = DYM == 2;
   __shared__ float4 dyq[2][DYQ_F4];                       // dL/dy halo, [cout quad][pixel (even | odd columns)][4]
   __shared__ __align__(16) float dyp[2][DYP_F + 16];      // dL/dy core, channel planes
   __shared__ __align__(16) float xp[2][XP_F + 16];        // a_in halo, channel planes
   __shared__ float4 wlds[16 * 64];                        // transform-domain dgrad weights, [xi][lane]
   __shared__ float red[4][16][2];
+  __shared__ float dtl[TAIL ? 2 * 400 : 4];               // tail: d loss / d sr around the tile, 20 x 20, zero outside the image
+  __shared__ float4 wout[TAIL ? 36 : 1];                  // tail: outlay weights, [tap][channel quad]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,15 +96,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
   const int t_hi = xcd_map ? t_lo + ntiles / 8 : ntiles;
   const int t_step = xcd_map ? G / 8 : G;
   const int t_first = t_lo + (xcd_map ? blockIdx.x / 8 : blockIdx.x);
-  auto tile_pos = [&](int tt, int& tb, int& txi, int& tyi) {
+  auto tile_pos = [&](int tt, int& tb, int& txi, int& tyi) __attribute__((always_inline)) {
     if (lgx >= 0) { tyi = (tt >> lgx) & (tiles_y - 1); tb = tt >> (lgx + lgy); txi = (tt + tyi + tb) & (tiles_x - 1); }
     else { txi = tt % tiles_x; const int r = tt / tiles_x; tyi = r % tiles_y; tb = r / tiles_y; }
   };
 
   for (int i = tid; i < 16 * 64; i += 512) wlds[i] = ld4(a.wpack_wino + 4 * (size_t)i);
+  if (TAIL && tid < 36) {
+    const float* wo = a.tail_w + (4 * (tid & 3)) * 9 + (tid >> 2);   // outlay weight [1][16][3][3]
+    wout[tid] = make_float4(wo[0], wo[9], wo[18], wo[27]);
+  }
 
   constexpr unsigned PXB = HS ? 32u : 64u;                // bytes per pixel (16 channels)
-  const __amdgpu_buffer_rsrc_t rg = mk_rsrc(a.g, npix * PXB);
+  const __amdgpu_buffer_rsrc_t rg = mk_rsrc(TAIL ? a.y : a.g, npix * PXB);
   const __amdgpu_buffer_rsrc_t ry = mk_rsrc(DYF ? a.y : a.g, npix * PXB);
   const __amdgpu_buffer_rsrc_t rx = mk_rsrc(a.x, npix * PXB);
   const __amdgpu_buffer_rsrc_t rbd = mk_rsrc(DYF && a.dy_border ? a.dy_border : const_cast<float*>(a.g), npix * PXB);
@@ -122,9 +134,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
   if (DYF) { csc = ld4(a.coef + 4 * cg); csh = ld4(a.coef + 16 + 4 * cg); ck1 = ld4(a.coef + 32 + 4 * cg); ck0 = ld4(a.coef + 48 + 4 * cg); }
   const bool xraw = a.x_scale == nullptr;
 
-  float4 pg[3], py[DYF ? 3 : 1], px_[3];                 // the tile in flight
+  float4 pg[TAIL ? 1 : 3], py[DYF ? 3 : 1], px_[3];      // the tile in flight
   int st_b = 0, st_tx = 0, st_ty = 0;                     // ... and its position
-  auto issue = [&](int tt) {
+  // tail: the d loss / d sr tile runs ONE TILE AHEAD of the others (its LDS copy has to be complete -- a barrier -- before
+  // write_stage forms g from it): element tid of the 20 x 20 tile, fp32 in every mode
+  const __amdgpu_buffer_rsrc_t rds = mk_rsrc(TAIL ? a.tail_dsr : a.x, TAIL ? npix * 4u : 4u);
+  float pd = 0.f;
+  const int dey = tid / 20, dex = tid - dey * 20;
+  auto issue_d = [&](int tt) __attribute__((always_inline)) {
+    int b, txi, tyi;
+    tile_pos(tt, b, txi, tyi);
+    const int gy = tyi * 16 - 2 + dey, gx = txi * 16 - 2 + dex;
+    const bool inside = tid < 400 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    pd = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rds, inside ? (int)((unsigned)((b * H + gy) * W + gx) * 4u) : (int)OOB, 0, 0));
+  };
+  auto write_d = [&](int buf) __attribute__((always_inline)) {
+    if (tid < 400) dtl[buf * 400 + tid] = pd;
+  };
+  auto issue = [&](int tt) __attribute__((always_inline)) {
     tile_pos(tt, st_b, st_tx, st_ty);
     const int x0 = st_tx * 16 - 1, y0 = st_ty * 16 - 1;
     const bool interior = st_tx > 0 && st_ty > 0 && st_tx + 1 < tiles_x && st_ty + 1 < tiles_y;
@@ -132,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
       const unsigned soff = (unsigned)((st_b * H + y0) * W + x0) * 64u;
 #pragma unroll
       for (int it = 0; it < 3; ++it) {
-        pg[it] = al4<HS>(rg, rel[it], soff);
+        if (!TAIL) pg[it] = al4<HS>(rg, rel[it], soff);
         if (DYF) py[it] = al4<HS>(ry, rel[it], soff);
         px_[it] = al4<HS>(rx, rel[it], soff);
       }
@@ -142,13 +169,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
         const int gy = y0 + spy[it], gx = x0 + spx[it];
         const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
         const unsigned pc = (unsigned)((st_b * H + clampi(gy, 0, H - 1)) * W + clampi(gx, 0, W - 1)) * 64u + (unsigned)cg * 16u;
-        pg[it] = al4<HS>(rg, inside ? pc : OOB, 0u);          // zero padding of dL/dy
+        if (!TAIL) pg[it] = al4<HS>(rg, inside ? pc : OOB, 0u);   // zero padding of dL/dy
         if (DYF) py[it] = al4<HS>(ry, inside ? pc : OOB, 0u);
         px_[it] = al4<HS>(rx, pc, 0u);                        // replicate padding of the forward input
       }
     }
   };
-  auto write_stage = [&](int buf) {
+  auto write_stage = [&](int buf) __attribute__((always_inline)) {
     const int x0 = st_tx * 16 - 1, y0 = st_ty * 16 - 1;
     const bool interior = st_tx > 0 && st_ty > 0 && st_tx + 1 < tiles_x && st_ty + 1 < tiles_y;
     float4* const Q = dyq[buf];
@@ -157,7 +184,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
       if (it == 2 && !slot2) continue;
-      float4 v = pg[it];
+      float4 v = pg[TAIL ? 0 : it];
+      if (TAIL) {
+        // g[c](q) = sum_t w[c][t] * S_t(q), S_t(q) = sum of d loss / d sr over the output pixels whose (clamped) tap t reads q
+        // (the adjoint of replicate padding, fused_edges.hip outlay_gather)
+        // (the adjoint of the clamp is separable: 12 FMAs on the 3x3 neighbourhood n of d loss / d sr, no branch -- fused_edges.hip)
+        const float* D = dtl + buf * 400 + (spy[it] + 1) * 20 + spx[it] + 1;
+        const int gy = y0 + spy[it], gx = x0 + spx[it];
+        const float ymf = gy == 0 ? 1.f : 0.f, ypf = gy == H - 1 ? 1.f : 0.f, xmf = gx == 0 ? 1.f : 0.f, xpf = gx == W - 1 ? 1.f : 0.f;
+        float n[3][3], cx[3][3], S[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) n[dy][dx] = D[(dy - 1) * 20 + dx - 1];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          cx[dy][0] = fmaf(xmf, n[dy][1], n[dy][2]);
+          cx[dy][1] = n[dy][1];
+          cx[dy][2] = fmaf(xpf, n[dy][1], n[dy][0]);
+        }
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          S[0 + tx] = fmaf(ymf, cx[1][tx], cx[2][tx]);
+          S[3 + tx] = cx[1][tx];
+          S[6 + tx] = fmaf(ypf, cx[1][tx], cx[0][tx]);
+        }
+        f32x2 gl = {0.f, 0.f}, gh = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float4 wq = wout[t * 4 + cg];
+          gl = __builtin_elementwise_fma((f32x2){wq.x, wq.y}, (f32x2){S[t], S[t]}, gl);
+          gh = __builtin_elementwise_fma((f32x2){wq.z, wq.w}, (f32x2){S[t], S[t]}, gh);
+        }
+        v = make_float4(gl[0], gl[1], gh[0], gh[1]);
+      }
       if (DYF) {
         v = bn_bwd4(v, py[it], csc, csh, ck1, ck0);
         if (!interior) {
@@ -217,14 +277,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
   // MFMAs instead of both staging while the matrix pipe idles (conv_wino8.hip does the same with its two wave teams).
   //   iteration j:   A: stage(j+1) -> loads(j+2) -> contract(j) -> barrier      B: contract(j) -> stage(j+1) -> loads(j+2) -> barrier
   // The barrier of iteration j publishes tile j+1 (other buffer) and retires every read of tile j's buffer.
-  auto tile_loop = [&](const bool stage_first, auto&& contract) {
+  auto tile_loop = [&](const bool stage_first, auto&& contract) __attribute__((always_inline)) {
     int t = t_first, buf = 0;
     if (t >= t_hi) { __syncthreads(); return; }           // (wlds barrier; workgroups without tiles exist only for tiny problems)
+    if (TAIL) issue_d(t);
     issue(t);
-    __syncthreads();                                      // wlds
+    if (TAIL) {
+      write_d(0);
+      if (t + t_step < t_hi) issue_d(t + t_step);
+    }
+    __syncthreads();                                      // wlds (tail: wout, d loss / d sr of tile 0)
     write_stage(0);
+    if (TAIL) write_d(1);
     int cb = st_b, txi = st_tx, tyi = st_ty;              // the tile being contracted
     if (t + t_step < t_hi) issue(t + t_step);
+    if (TAIL && t + 2 * t_step < t_hi) issue_d(t + 2 * t_step);
     __syncthreads();                                      // tile 0 staged
     while (true) {
       const int t_next = t + t_step;
@@ -237,7 +304,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
         SIFSR_DIAG_WAIT_LOADS(cw);
         SIFSR_DIAG_ACC16(8, cw);
         write_stage(buf ^ 1);
+        if (TAIL) write_d(buf);                           // d loss / d sr of tile j+2 (tile j's copy was last read before the previous barrier)
         if (t_next + t_step < t_hi) issue(t_next + t_step);
+        if (TAIL && t_next + 2 * t_step < t_hi) issue_d(t_next + 2 * t_step);
       }
       SIFSR_DIAG_T(c1);
       contract(buf, cb, txi, tyi);
@@ -246,7 +315,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
         SIFSR_DIAG_WAIT_LOADS(cw);
         SIFSR_DIAG_ACC16(9, cw);
         write_stage(buf ^ 1);
+        if (TAIL) write_d(buf);
         if (t_next + t_step < t_hi) issue(t_next + t_step);
+        if (TAIL && t_next + 2 * t_step < t_hi) issue_d(t_next + 2 * t_step);
       }
       SIFSR_DIAG_T(c3);
       if (!more) break;
@@ -459,7 +530,9 @@ int conv3x3_bwd16_grid(int B, int H, int W) {
 
 int launch_conv3x3_bwd16(const Bwd16Args& a, hipStream_t s) {
   if (!conv3x3_bwd16_applies(a.B, a.H, a.W)) return SIFSR_ERR_SHAPE;
-  if (!a.x || !a.g || !a.wpack_wino || !a.gin || !a.slabs) return SIFSR_ERR_ARG;
+  if (!a.x || !a.wpack_wino || !a.gin || !a.slabs) return SIFSR_ERR_ARG;
+  const bool tail = a.tail_dsr != nullptr;
+  if (tail ? (!a.tail_w || !a.y || !a.coef) : !a.g) return SIFSR_ERR_ARG;
   if ((a.y != nullptr) != (a.coef != nullptr) || (a.x_scale != nullptr) != (a.x_shift != nullptr)) return SIFSR_ERR_ARG;
   if (a.stat_partials != nullptr && (!a.bn_y || !a.bn_scale || !a.bn_shift)) return SIFSR_ERR_ARG;
   // the BatchNorm sums are taken from the staged input tile: the layer below IS the layer whose raw output is the input
@@ -470,11 +543,13 @@ int launch_conv3x3_bwd16(const Bwd16Args& a, hipStream_t s) {
   const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
   const dim3 grid(conv3x3_bwd16_grid(a.B, a.H, a.W)), block(512);
   if (a.half) {
-    if (a.y != nullptr) hipLaunchKernelGGL((conv3x3_bwd16_kernel<true, true>), grid, block, 0, s, a, ntiles, lgx, lgy);
-    else hipLaunchKernelGGL((conv3x3_bwd16_kernel<false, true>), grid, block, 0, s, a, ntiles, lgx, lgy);
+    if (tail) hipLaunchKernelGGL((conv3x3_bwd16_kernel<2, true>), grid, block, 0, s, a, ntiles, lgx, lgy);
+    else if (a.y != nullptr) hipLaunchKernelGGL((conv3x3_bwd16_kernel<1, true>), grid, block, 0, s, a, ntiles, lgx, lgy);
+    else hipLaunchKernelGGL((conv3x3_bwd16_kernel<0, true>), grid, block, 0, s, a, ntiles, lgx, lgy);
   } else {
-    if (a.y != nullptr) hipLaunchKernelGGL((conv3x3_bwd16_kernel<true, false>), grid, block, 0, s, a, ntiles, lgx, lgy);
-    else hipLaunchKernelGGL((conv3x3_bwd16_kernel<false, false>), grid, block, 0, s, a, ntiles, lgx, lgy);
+    if (tail) hipLaunchKernelGGL((conv3x3_bwd16_kernel<2, false>), grid, block, 0, s, a, ntiles, lgx, lgy);
+    else if (a.y != nullptr) hipLaunchKernelGGL((conv3x3_bwd16_kernel<1, false>), grid, block, 0, s, a, ntiles, lgx, lgy);
+    else hipLaunchKernelGGL((conv3x3_bwd16_kernel<0, false>), grid, block, 0, s, a, ntiles, lgx, lgy);
   }
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;

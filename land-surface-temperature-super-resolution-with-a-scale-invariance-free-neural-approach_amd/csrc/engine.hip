@@ -467,25 +467,32 @@ int conv_unit_dgrad(const Ctx& c, int l, const float* dy, float* g0, int C0, int
 // Returns SIFSR_OK with *applied = false when the separate kernels have to run instead (other shapes, bf16 mode, switched off).
 // The kernel runs on the CALLER's stream (it is part of the serial chain); its weight-gradient slabs join the Winograd
 // reduction list, and ev[l] of the second stream's lane marks their completion for a reduction issued there.
-int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin, const float* addend, int bn_layer, int* stat_rows,
-                    bool dy_stored, bool* applied) {
+bool bwd16_usable(const Ctx& c, int l, ConvSrc s0) {
   const LayerInfo& L = c.nt.L[l];
-  *applied = false;
-  if (stat_rows) *stat_rows = 0;
-  const int lh = c.lvH(L.level), lw = c.lvW(L.level);
   // bf16 mode: the fused kernel exists for bf16 STORAGE too (fp32 Winograd arithmetic on widened values), but there it LOSES:
   // 14,450 against 15,900 patches/s on the bf16 step -- with half the bytes its fp32 matrix + transform work is the bottleneck,
   // while the separate bf16 kernels contract with 16x cheaper MFMAs.  SIFSR_BF16_BWD16=1 selects it for A/B.
   static const int bf16_fused = getenv("SIFSR_BF16_BWD16") ? atoi(getenv("SIFSR_BF16_BWD16")) : 0;
-  if (L.cin != 16 || L.cout != 16 || (c.bf16 != 0 && !bf16_fused) || c.xjobs == nullptr || !wgrad_wino_policy(16, 16) || s0.C != 16 || s0.coff != 0 ||
-      !conv3x3_bwd16_applies(c.B, lh, lw))
-    return SIFSR_OK;
+  return L.cin == 16 && L.cout == 16 && (c.bf16 == 0 || bf16_fused) && c.xjobs != nullptr && wgrad_wino_policy(16, 16) && s0.C == 16 &&
+         s0.coff == 0 && conv3x3_bwd16_applies(c.B, c.lvH(L.level), c.lvW(L.level));
+}
+// dy_mode 0: `dy` is dL/dy itself.  1: `dy` is g = dL/d relu(bn(y_l)), dL/dy formed while staging.  2 (l = ub3.convbloc.bloc.3): `dy` is
+// d loss / d sr and g the input gradient of outlay, recomputed while staging (no tail_bwd_apply pass).
+int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin, const float* addend, int bn_layer, int* stat_rows,
+                    int dy_mode, bool* applied) {
+  const LayerInfo& L = c.nt.L[l];
+  *applied = false;
+  if (stat_rows) *stat_rows = 0;
+  const int lh = c.lvH(L.level), lw = c.lvW(L.level);
+  if (!bwd16_usable(c, l, s0)) return dy_mode == 2 ? SIFSR_ERR_ARG : SIFSR_OK;
+  const bool dy_stored = dy_mode == 0;
   const bool fuse = bn_layer >= 0 && addend == nullptr && c.nt.L[bn_layer].cout == 16 && c.nt.L[bn_layer].level == L.level;
   const int grid = conv3x3_bwd16_grid(c.B, lh, lw);
   if ((size_t)grid * 16 * 256 > c.lay.slab_cap[l] || (fuse && (size_t)grid * 32 > c.lay.partials_cap)) return SIFSR_ERR_WORKSPACE;
   Bwd16Args a;
   a.x = s0.ptr; a.x_scale = s0.scale; a.x_shift = s0.shift;
-  a.g = dy;
+  if (dy_mode == 2) { a.tail_dsr = dy; a.tail_w = c.params + c.nt.out_w_off; }
+  else a.g = dy;
   if (!dy_stored) { a.y = c.f(c.lay.y[l]); a.coef = c.f(c.lay.coef_f) + 4 * (size_t)L.ch_off; a.dy_border = c.f(c.lay.dy_border); }
   a.wpack_wino = c.f(c.lay.wwd) + (size_t)L.wpack_off / 9 * 16;
   a.gin = gin; a.addend = addend;
@@ -614,22 +621,28 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   SideLaneGuard lane_guard(c.side, s);
   c.forked = &lane_guard.forked;
 
+  static const int tail_apply_forced = getenv("SIFSR_TAIL_APPLY") ? atoi(getenv("SIFSR_TAIL_APPLY")) : 0;   // 1: keep the separate second pass (A/B)
+  bool tail_in_bwd16 = false;
   // outlay backward fused with the BatchNorm+ReLU backward of ub3.convbloc.bloc.3 (fused_edges.hip): the outlay
   // input gradient is recomputed from dsr in both passes instead of being stored; dy(L_U3B) -> g[L_U3B]
   {
     const LayerInfo& L = nt.L[L_U3B];
     int nblk = B * ((H + 15) / 16) * ((W + 15) / 16);
-    if (nblk > 1024) nblk = 1024;
+    if (nblk > 768) nblk = 768;   // persistent: three 168-register workgroups per CU (fused_edges.hip)
     const float* y = c.f(w.y[L_U3B]);
     SIFSR_TRY(launch_tail_bwd_reduce(y, c.scale(L_U3B), c.shift(L_U3B), c.f(w.mean) + L.ch_off, c.f(w.invstd) + L.ch_off, dsr,
                                      params + nt.out_w_off, c.f(w.slabs), c.f(w.partials), nblk, B, H, W, s));
     if (grads + nt.out_b_off != grads + nt.out_w_off + 144) return SIFSR_ERR_ARG;
     SIFSR_TRY(launch_sum_partials(c.f(w.slabs), nblk, 145, grads + nt.out_w_off, s));
+    // with the fused 16 -> 16 backward kernel the second pass is part of that kernel's staging (conv_bwd16.hip, mode 2)
+    tail_in_bwd16 = !tail_apply_forced && bwd16_usable(c, L_U3B, src_act(c, L_U3A));
     SIFSR_TRY(launch_bn_bwd_finalize(c.f(w.partials), nblk, 16, (double)w.npix[0], c.scale(L_U3B), c.f(w.mean) + L.ch_off,
                                      c.f(w.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
-                                     reinterpret_cast<double*>(c.f(w.coef)), s));
-    SIFSR_TRY(launch_tail_bwd_apply(y, c.scale(L_U3B), c.shift(L_U3B), reinterpret_cast<const double*>(c.f(w.coef)), dsr,
-                                    params + nt.out_w_off, c.f(w.g[L_U3B]), B, H, W, s));
+                                     reinterpret_cast<double*>(c.f(w.coef)), s, c.shift(L_U3B), params + L.beta_off,
+                                     c.f(w.coef_f) + 4 * (size_t)L.ch_off));
+    if (!tail_in_bwd16)
+      SIFSR_TRY(launch_tail_bwd_apply(y, c.scale(L_U3B), c.shift(L_U3B), reinterpret_cast<const double*>(c.f(w.coef)), dsr,
+                                      params + nt.out_w_off, c.f(w.g[L_U3B]), B, H, W, s));
   }
 
   // decoder, last to first
@@ -646,7 +659,8 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     if (k != 2) SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), grads, nullptr, up_rows, 0));
     int rows_a = 0;
     bool fused_b = false;
-    SIFSR_TRY(conv_unit_bwd16(c, lb, src_act(c, la), c.f(w.g[lb]), c.f(w.g[la]), nullptr, la, &rows_a, k == 2, &fused_b));
+    SIFSR_TRY(conv_unit_bwd16(c, lb, src_act(c, la), k == 2 && tail_in_bwd16 ? dsr : c.f(w.g[lb]), c.f(w.g[la]), nullptr, la, &rows_a,
+                              k == 2 ? (tail_in_bwd16 ? 2 : 0) : 1, &fused_b));
     if (!fused_b) {
       SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads, k == 2));
       SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), nt.L[la].cout, nt.L[lb].cin, nullptr, 0, nullptr, la, &rows_a, k == 2));
@@ -679,14 +693,14 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     // residual DoubleConvolution (g[lb] survives untouched: it is also the skip gradient added to gP[k] below)
     SIFSR_TRY(bn_unit_bwd(c, lb, c.f(w.g[lb]), grads, nullptr, rows_b));
     bool fused_b = false;
-    SIFSR_TRY(conv_unit_bwd16(c, lb, src_act(c, la), c.f(w.g[lb]), c.f(w.g[la]), nullptr, la, &rows_a, false, &fused_b));
+    SIFSR_TRY(conv_unit_bwd16(c, lb, src_act(c, la), c.f(w.g[lb]), c.f(w.g[la]), nullptr, la, &rows_a, 1, &fused_b));
     if (!fused_b) {
       SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads));
       SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), pc[k], pc[k], nullptr, 0, nullptr, la, &rows_a));
     }
     SIFSR_TRY(bn_unit_bwd(c, la, c.f(w.g[la]), grads, nullptr, rows_a));
     bool fused_a = false;
-    SIFSR_TRY(conv_unit_bwd16(c, la, src_raw(c.f(w.P[k]), pc[k]), c.f(w.g[la]), c.f(w.gP[k]), c.f(w.g[lb]), -1, nullptr, false, &fused_a));
+    SIFSR_TRY(conv_unit_bwd16(c, la, src_raw(c.f(w.P[k]), pc[k]), c.f(w.g[la]), c.f(w.gP[k]), c.f(w.g[lb]), -1, nullptr, 1, &fused_a));
     if (!fused_a) {
       SIFSR_TRY(conv_unit_wgrad(c, la, src_raw(c.f(w.P[k]), pc[k]), src_none(), c.f(w.g[la]), grads));
       SIFSR_TRY(conv_unit_dgrad(c, la, c.f(w.g[la]), c.f(w.gP[k]), pc[k], pc[k], nullptr, 0, c.f(w.g[lb])));
@@ -699,7 +713,7 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   SIFSR_TRY(bn_unit_bwd(c, L_IN3, c.f(w.g[L_IN3]), grads, c.f(w.gP[0])));
   int rows_in0 = 0;
   bool fused_in3 = false;
-  SIFSR_TRY(conv_unit_bwd16(c, L_IN3, src_act(c, L_IN0), c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), nullptr, L_IN0, &rows_in0, false, &fused_in3));
+  SIFSR_TRY(conv_unit_bwd16(c, L_IN3, src_act(c, L_IN0), c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), nullptr, L_IN0, &rows_in0, 1, &fused_in3));
   if (!fused_in3) SIFSR_TRY(conv_unit_wgrad(c, L_IN3, src_act(c, L_IN0), src_none(), c.f(w.g[L_IN3]), grads));
   // that was the last MFMA layer: all 16 layers' weight-gradient slabs -> OIHW gradients, one launch.  With the second
   // stream it follows the last weight gradient there (it writes only the conv-weight regions of `grads`, which nothing

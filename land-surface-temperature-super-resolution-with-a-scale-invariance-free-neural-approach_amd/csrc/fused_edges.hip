@@ -9,9 +9,6 @@
 
 namespace {
 
-#define TAIL_ABL 0
-constexpr int OCS = 20;   // LDS pixel stride of the y halo tile (floats): conflict-free b128 reads
-
 // S_t(q) = sum of dsr[p] over the output pixels p whose (clamped) tap t reads input pixel q -- the adjoint of
 // replicate padding.  dt = 18x18 LDS tile of dsr around the 16x16 tile of q, ZERO outside the image;
 // (ly, lx) = q inside the tile; ym/yp/xm/xp: q lies on the first/last image row/column.
@@ -40,200 +37,174 @@ __device__ __forceinline__ void stage_dsr_halo(float* dt, const float* __restric
   }
 }
 
-// One S value for a runtime tap t -- the B operand of the matrix-core form of the outlay input gradient.
-// `off` = the interior offset (1 - ty) * 18 + (1 - tx) of tap t, precomputed per lane.
-__device__ __forceinline__ float outlay_S1(const float* dt, int ly, int lx, int t, int off, bool border, int gy, int gx,
-                                           int H, int W) {
-  float s = dt[ly * 18 + lx + off];
-  if (border) {
-    const int ty = t / 3 - 1, tx = t - (ty + 1) * 3 - 1;
-    const int ry = ly + 1 - ty, rx = lx + 1 - tx;
-    const bool cy = (ty == -1 && gy == 0) || (ty == 1 && gy == H - 1);
-    const bool cx = (tx == -1 && gx == 0) || (tx == 1 && gx == W - 1);
-    if (cx) s += dt[ry * 18 + lx + 1];
-    if (cy) s += dt[(ly + 1) * 18 + rx];
-    if (cx && cy) s += dt[(ly + 1) * 18 + lx + 1];
-  }
-  return s;
-}
-
-// Pass 1.  Persistent workgroups over 16x16 tiles, software-pipelined (next tile's halo in registers while the
-// current one is processed out of LDS; <= 128 VGPRs so four workgroups per CU keep enough bytes in flight).
-// Two matrix-core contractions per tile:
-//   outlay dW[ci][t]  = sum_{halo px p'} a[p'][ci] * dsr[p' - t]        (A lane (ci, p'), B lane (t, p'))
-//   g[ci][q]          = sum_t w[ci][t] * S_t(q)                          (A lane (ci, t),  B lane (q, t))
-// the D fragment of the second (4 channels x 1 pixel per lane) is consumed in registers by the BatchNorm
-// reduction: dz = g*[z>0]; sum dz and sum dz*y per channel (fp32 per lane over the workgroup's tiles -- a few
-// hundred terms -- float64 across lanes, waves and workgroups).
-template <bool HS>   // HS: y stored as bf16 (the bf16 compute mode, common.h)
-__global__ __launch_bounds__(256, 2) void tail_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+// Pass 1.  With S_t(q) (above) both contractions are sums over the INPUT pixels q of the same nine values:
+//   outlay dW[ci][t] = sum_q a[q][ci] * S_t(q)          g[q][ci] = sum_t w[ci][t] * S_t(q)
+// so a work item = (pixel q, channel quad) needs y[q][4 channels] -- one coalesced float4 straight from HBM, no halo of y, no
+// LDS tile of it -- and the 3x3 neighbourhood of d loss / d sr around q (LDS, 18x18 per 16x16 tile, double-buffered: one barrier
+// per tile).  Per item 20 + 18 packed FMAs (dW accumulators [4][9 (+1)] per lane; g) and the BatchNorm sums dz = g*[z>0]: sum dz,
+// sum dz*y.  (Rounds 1-2 ran both contractions on the matrix cores -- 138 v_mfma_f32_16x16x4 per tile with 7 of 16 columns of
+// the dW product empty, ~75 us each; an fp32 MFMA moves 32 FMAs per cycle and SIMD, exactly what v_pk_fma_f32 does, and the
+// operands of the VALU form need no staging: 169 -> see DESIGN.md section 4.3.)
+// Persistent workgroups over 16x16 tiles (the last ones may be partial); the next tile's y quads and d loss / d sr halo are in
+// flight while the current tile is processed.  fp32 per lane over the workgroup's tiles (a few dozen terms), float64 across
+// lanes, waves and workgroups.
+// HS: y stored as bf16 (the bf16 compute mode, common.h).  FULL: H and W are multiples of 16 (no partial tiles: `inside` is true)
+template <bool HS, bool FULL>
+__global__ __launch_bounds__(256, 3) void tail_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift,
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd,
                                                                  const float* __restrict__ dsr, const float* __restrict__ w,
                                                                  float* __restrict__ wpart, float* __restrict__ bnpart,
                                                                  int B, int H, int W) {
-  __shared__ float tile[18 * 20 * OCS];   // RAW y halo tile, [row][col (18 + 2 pad)][OCS]
-  __shared__ float dt[324];
-  __shared__ float red[4][256];
-  __shared__ float bsum[4];
-  __shared__ double dred[4][4][8];        // [wave][channel quad][sum dz x4 | sum dz*y x4]
+  __shared__ float dt[2][328];
+  __shared__ double dred[4][4][48];       // [wave][channel quad][dW 4 x 9 | db | pad | sum dz x4 | sum dz*y x4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16, ntiles = B * tiles_x * tiles_y;   // last ones may be partial
-  const int i16 = lane & 15, k = lane >> 4;
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16, ntiles = B * tiles_x * tiles_y;
+  const int c4 = tid & 3, pl = tid >> 2;                 // channel quad; pixel slot: items = pixels pl + 64 * k of the tile, k < 4
+  const int lx = pl & 15, ly0 = pl >> 4;                 // ... = (row ly0 + 4 k, column lx)
 
-  // ---- outlay dW operands
-  const int tty = i16 < 9 ? i16 / 3 : 100, ttx = i16 < 9 ? i16 % 3 : 100;
-  const float sci = scale[i16], shi = shift[i16];
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float4 sc4 = ld4(scale + 4 * c4), sh4 = ld4(shift + 4 * c4);
+  const f32x2 scl = {sc4.x, sc4.y}, sch = {sc4.z, sc4.w}, shl = {sh4.x, sh4.y}, shh = {sh4.z, sh4.w};
+  f32x2 wl[9], wh[9];                                    // outlay weight [1][16][3][3]: (w[4 c4 + 0..1][t]), (w[4 c4 + 2..3][t])
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float* wo = w + (4 * c4) * 9 + t;
+    wl[t] = (f32x2){wo[0], wo[9]}; wh[t] = (f32x2){wo[18], wo[27]};
+  }
+  f32x2 acc[4][5];                                       // dW[4 c4 + j][2 u, 2 u + 1]  (u = 4: tap 8 | unused)
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int u = 0; u < 5; ++u) acc[j][u] = (f32x2){0.f, 0.f};
+  f32x2 t1l = {0.f, 0.f}, t1h = t1l, t2l = t1l, t2h = t1l;
   float bacc = 0.f;
 
-  // ---- g operands: A = w[ci = i16][t = 4*kk + k] (t >= 9 -> 0); B tap of this lane per k-step kk
-  float wa[3];
-  int boff[3];
-#pragma unroll
-  for (int kk = 0; kk < 3; ++kk) {
-    const int t = 4 * kk + k;
-    wa[kk] = t < 9 ? w[i16 * 9 + t] : 0.f;
-    boff[kk] = t < 9 ? (2 - t / 3) * 18 + (2 - t % 3) : 19;
-  }
-  // BatchNorm: this lane owns channels 4k..4k+3 (the D rows) of pixel column i16
-  const float4 sc = ld4(scale + 4 * k), sh = ld4(shift + 4 * k);
-  const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-  float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
-
-  // ---- staging: element e = tid + 256*i of the 18 x 18 x 4 float4 halo (i < 6), e of the 18 x 18 dsr halo (i < 2)
-  float4 py[6];
+  float4 py[4];
   float pd[2];
-  auto fetch = [&](int tl) {
-    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, b = tl / (tiles_x * tiles_y);
+  size_t nbase = 0;                                      // next tile: element offset of its item 0, row step (0 past the last image row)
+  int nrow[4] = {0, 0, 0, 0};
+  auto fetch_y = [&](int k) __attribute__((always_inline)) { py[k] = ldA4<HS>(y, nbase + (size_t)nrow[k]); };
+  auto fetch = [&](int tl) __attribute__((always_inline)) {
+    const int tx = tl % tiles_x, r = tl / tiles_x, ty = r % tiles_y, b = r / tiles_y;
     const int x0 = tx * 16, y0 = ty * 16;
-    const bool border = tx == 0 || ty == 0 || tx == tiles_x - 1 || ty == tiles_y - 1;
-    if (!border) {
-      const size_t yb = ((size_t)(b * H + y0 - 1) * W + x0 - 1) * 16;
-      const float* db = dsr + (size_t)(b * H + y0 - 1) * W + x0 - 1;
+    const int gx = min(x0 + lx, W - 1);
+    nbase = ((size_t)(b * H) * W + gx) * 16 + 4 * c4;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int e = tid + 256 * i;
-        if (e < 324 * 4) {
-          const int hy = (e >> 2) / 18;
-          py[i] = ldA4<HS>(y, yb + (size_t)(hy * (W - 18) * 16 + e * 4));   // ((hy*W + hx)*16 + 4*q4), e = (hy*18 + hx)*4 + q4
-        }
-      }
+    for (int k = 0; k < 4; ++k) nrow[k] = min(y0 + ly0 + 4 * k, H - 1) * W * 16;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = tid + 256 * i;
-        if (e < 324) pd[i] = db[(e / 18) * (W - 18) + e];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int e = tid + 256 * i;
-        if (e < 324 * 4) {
-          const int p = e >> 2, hy = p / 18, hx = p - hy * 18;
-          const int gy = clampi(y0 - 1 + hy, 0, H - 1), gx = clampi(x0 - 1 + hx, 0, W - 1);
-          py[i] = ldA4<HS>(y, ((size_t)(b * H + gy) * W + gx) * 16 + 4 * (e & 3));
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = tid + 256 * i;
-        if (e < 324) {
-          const int hy = e / 18, hx = e - hy * 18;
-          const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-          pd[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? dsr[(size_t)(b * H + gy) * W + gx] : 0.f;
-        }
-      }
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 256 * i;
+      const int hy = e / 18, hx = e - hy * 18;
+      const int qy = y0 - 1 + hy, qx = x0 - 1 + hx;
+      const float v = dsr[(size_t)(b * H + clampi(qy, 0, H - 1)) * W + clampi(qx, 0, W - 1)];   // (no branch: select after the load)
+      pd[i] = (e < 324 && qy >= 0 && qy < H && qx >= 0 && qx < W) ? v : 0.f;
     }
   };
 
-  for (int e = tid; e < 18 * 20 * OCS; e += 256) tile[e] = 0.f;
-  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
-  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+  int buf = 0;
+  if ((int)blockIdx.x < ntiles) {
+    fetch(blockIdx.x);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fetch_y(k);
+  }
+  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x, buf ^= 1) {
     const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y;
     const int x0 = tx * 16, y0 = ty * 16;
-    const bool border = tx == 0 || ty == 0 || tx == tiles_x - 1 || ty == tiles_y - 1;
-    __syncthreads();
+    const float xmf = (x0 + lx == 0) ? 1.f : 0.f, xpf = (x0 + lx == W - 1) ? 1.f : 0.f;
+    dt[buf][tid] = pd[0];
+    if (tid + 256 < 324) dt[buf][tid + 256] = pd[1];
+    __syncthreads();          // (one barrier per tile: the other buffer was last read before the previous barrier)
+    // (past the last tile the same tile is fetched again: straight-line code, the compiler keeps the items apart)
+    fetch(tl + (int)gridDim.x < ntiles ? tl + (int)gridDim.x : tl);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int e = tid + 256 * i;
-      if (e < 324 * 4) {
-        const int hy = (e >> 2) / 18;
-        // LDS offset (hy*20 + hx)*OCS + 4*q4 with e = (hy*18 + hx)*4 + q4:  5*e - q4 + 40*hy
-        *reinterpret_cast<float4*>(&tile[5 * e - (e & 3) + 40 * hy]) = py[i];
+    for (int k = 0; k < 4; ++k) {
+      const float4 yv = py[k];                           // this tile's item k; its register takes the next tile's right away
+      fetch_y(k);
+      __builtin_amdgcn_sched_barrier(0);                 // (items one after the other: interleaved they need 204 registers)
+      const int ly = ly0 + 4 * k;
+      const float* D = &dt[buf][(ly + 1) * 18 + lx + 1];
+      // S_t(q), t = (ty, tx): the adjoint of the clamp is separable -- tap tx = -1 reads column qx from output columns qx + 1 and,
+      // on the first image column, qx itself; tx = +1 from qx - 1 and, on the last column, qx; likewise the rows.  n = the 3x3
+      // neighbourhood of d loss / d sr around q (zero outside the image); 12 FMAs, no branch, on every tile.
+      float n[3][3], cx[3][3], S[10];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) n[dy][dx] = D[(dy - 1) * 18 + dx - 1];
+      const float ymf = (y0 + ly == 0) ? 1.f : 0.f, ypf = (y0 + ly == H - 1) ? 1.f : 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        cx[dy][0] = fmaf(xmf, n[dy][1], n[dy][2]);       // tx = -1
+        cx[dy][1] = n[dy][1];
+        cx[dy][2] = fmaf(xpf, n[dy][1], n[dy][0]);       // tx = +1
       }
-    }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      if (tid + 256 * i < 324) dt[tid + 256 * i] = pd[i];
-    __syncthreads();
-    if (tl + (int)gridDim.x < ntiles) fetch(tl + gridDim.x);
-
-    bacc += dt[((tid >> 4) + 1) * 18 + (tid & 15) + 1];
-    // outlay dW: this wave takes halo rows wave, wave+4, ...
-#pragma unroll 1
-    for (int row = (TAIL_ABL & 1) ? 100 : wave; row < 18; row += 4) {
-      const int oy = row - tty;
-      const bool vy = oy >= 0 && oy < 16;
-      const float* arow = &tile[row * 20 * OCS + k * OCS + i16];
-      const float* brow = &dt[(oy + 1) * 18 + k - ttx + 1];
-#pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        const float av = fmaxf(fmaf(arow[4 * q * OCS], sci, shi), 0.f);
-        const int ox = 4 * q + k - ttx;
-        const bool vx = (q == 0) ? ox >= 0 : (q == 4 ? (ox < 16 && ttx < 3) : ttx < 3);
-        const float bv = (vy && vx) ? brow[4 * q] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+      for (int tx_ = 0; tx_ < 3; ++tx_) {
+        S[0 + tx_] = fmaf(ymf, cx[1][tx_], cx[2][tx_]);  // ty = -1
+        S[3 + tx_] = cx[1][tx_];
+        S[6 + tx_] = fmaf(ypf, cx[1][tx_], cx[0][tx_]);  // ty = +1
       }
-    }
-    // g on the matrix cores, BatchNorm sums from the D fragment: this wave takes tile rows 4*wave .. 4*wave+3
-#pragma unroll 2
-    for (int gi = (TAIL_ABL & 2) ? 4 : 0; gi < 4; ++gi) {
-      const int ly = 4 * wave + gi, lx = i16;
-      f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+      S[9] = 0.f;
+      const bool inside = FULL || (y0 + ly < H && x0 + lx < W);    // partial tiles: pixels past the image stay out of every sum
+      const f32x2 yl = {yv.x, yv.y}, yh = {yv.z, yv.w};
+      const f32x2 zl = __builtin_elementwise_fma(yl, scl, shl), zh = __builtin_elementwise_fma(yh, sch, shh);
+      const float a[4] = {inside ? fmaxf(zl[0], 0.f) : 0.f, inside ? fmaxf(zl[1], 0.f) : 0.f, inside ? fmaxf(zh[0], 0.f) : 0.f,
+                          inside ? fmaxf(zh[1], 0.f) : 0.f};
 #pragma unroll
-      for (int kk = 0; kk < 3; ++kk) {
-        float bv = outlay_S1(dt, ly, lx, 4 * kk + k, boff[kk], border && 4 * kk + k < 9, y0 + ly, x0 + lx, H, W);
-        if (kk == 2 && k != 0) bv = 0.f;
-        g = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[kk], bv, g, 0, 0, 0);
-      }
-      const float4 yv = *reinterpret_cast<const float4*>(&tile[((ly + 1) * 20 + lx + 1) * OCS + 4 * k]);
-      const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
-      const bool inside = y0 + ly < H && x0 + lx < W;      // partial tiles: pixels past the image stay out of the sums
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float dz = (inside && fmaf(yy[j], scv[j], shv[j]) > 0.f) ? g[j] : 0.f;
-        t1[j] += dz;
-        t2[j] = fmaf(dz, yy[j], t2[j]);
+        for (int u = 0; u < 5; ++u) acc[j][u] = __builtin_elementwise_fma((f32x2){a[j], a[j]}, (f32x2){S[2 * u], S[2 * u + 1]}, acc[j][u]);
+      f32x2 gl = {0.f, 0.f}, gh = {0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        gl = __builtin_elementwise_fma(wl[t], (f32x2){S[t], S[t]}, gl);
+        gh = __builtin_elementwise_fma(wh[t], (f32x2){S[t], S[t]}, gh);
       }
+      const f32x2 dl = {(inside && zl[0] > 0.f) ? gl[0] : 0.f, (inside && zl[1] > 0.f) ? gl[1] : 0.f};
+      const f32x2 dh = {(inside && zh[0] > 0.f) ? gh[0] : 0.f, (inside && zh[1] > 0.f) ? gh[1] : 0.f};
+      t1l += dl; t1h += dh;
+      t2l = __builtin_elementwise_fma(dl, yl, t2l); t2h = __builtin_elementwise_fma(dh, yh, t2h);
+      bacc += D[0];                                      // (every channel quad sums d loss / d sr: quad 0's sum is the bias gradient)
     }
   }
 
-  // outlay dW [ci][t] and db
+  // ---- across the 16 lanes of a channel quad (lane = 4 * pixel slot + c4), in float64; then waves, then workgroups
+  auto quad_sum = [&](float v) __attribute__((always_inline)) {
+    double d = (double)v;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[wave][(4 * k + r) * 16 + i16] = acc[r];
+    for (int m = 4; m < 64; m <<= 1) d += __shfl_xor(d, m);
+    __builtin_amdgcn_sched_barrier(0);                   // (one reduction after the other: 45 interleaved ones set the kernel's register count)
+    return d;
+  };
 #pragma unroll
-  for (int m = 1; m < 64; m <<= 1) bacc += __shfl_xor(bacc, m);
-  if (lane == 0) bsum[wave] = bacc;
-  // BatchNorm sums: reduce over the 16 pixel lanes of each channel quad, then over the 4 waves
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    double a1 = (double)t1[j], a2 = (double)t2[j];
+    for (int t = 0; t < 9; ++t) {
+      const double d = quad_sum(acc[j][t >> 1][t & 1]);
+      if (lane < 4) dred[wave][c4][j * 9 + t] = d;
+    }
+  {
+    const double d = quad_sum(bacc);
+    if (lane < 4) dred[wave][c4][36] = d;
+    const float t1[4] = {t1l[0], t1l[1], t1h[0], t1h[1]}, t2[4] = {t2l[0], t2l[1], t2h[0], t2h[1]};
 #pragma unroll
-    for (int m = 1; m < 16; m <<= 1) { a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
-    if (i16 == 0) { dred[wave][k][j] = a1; dred[wave][k][4 + j] = a2; }
+    for (int j = 0; j < 4; ++j) {
+      const double d1 = quad_sum(t1[j]), d2 = quad_sum(t2[j]);
+      if (lane < 4) { dred[wave][c4][40 + j] = d1; dred[wave][c4][44 + j] = d2; }
+    }
   }
   __syncthreads();
+  auto wsum = [&](int q, int i) __attribute__((always_inline)) { return dred[0][q][i] + dred[1][q][i] + dred[2][q][i] + dred[3][q][i]; };
   if (tid < 144) {
     const int ci = tid / 9, t = tid % 9;
-    wpart[(size_t)blockIdx.x * 145 + tid] = red[0][ci * 16 + t] + red[1][ci * 16 + t] + red[2][ci * 16 + t] + red[3][ci * 16 + t];
+    wpart[(size_t)blockIdx.x * 145 + tid] = (float)wsum(ci >> 2, (ci & 3) * 9 + t);
   } else if (tid == 144) {
-    wpart[(size_t)blockIdx.x * 145 + 144] = bsum[0] + bsum[1] + bsum[2] + bsum[3];
+    wpart[(size_t)blockIdx.x * 145 + 144] = (float)wsum(0, 36);
   } else if (tid >= 192 && tid < 208) {
     // channel c: sum dz and sum dz*xhat = invstd * (sum dz*y - mean * sum dz), in float64
     const int c = tid - 192, q = c >> 2, j = c & 3;
-    const double s1 = dred[0][q][j] + dred[1][q][j] + dred[2][q][j] + dred[3][q][j];
-    const double s2 = dred[0][q][4 + j] + dred[1][q][4 + j] + dred[2][q][4 + j] + dred[3][q][4 + j];
+    const double s1 = wsum(q, 40 + j), s2 = wsum(q, 44 + j);
     bnpart[((size_t)blockIdx.x * 16 + c) * 2 + 0] = (float)s1;
     bnpart[((size_t)blockIdx.x * 16 + c) * 2 + 1] = (float)((double)invstd[c] * (s2 - (double)mean[c] * s1));
   }
@@ -289,8 +260,11 @@ int launch_tail_bwd_reduce(const float* y, const float* scale, const float* shif
                            const float* dsr, const float* w, float* wpart, float* bnpart, int nblk, int B, int H, int W,
                            hipStream_t s) {
   if (H < 3 || W < 3 || nblk < 1) return SIFSR_ERR_SHAPE;
-  if (sifsr_half_storage()) hipLaunchKernelGGL(tail_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, s, y, scale, shift, mean, invstd, dsr, w, wpart, bnpart, B, H, W);
-  else hipLaunchKernelGGL(tail_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, y, scale, shift, mean, invstd, dsr, w, wpart, bnpart, B, H, W);
+  const bool full = H % 16 == 0 && W % 16 == 0;
+#define TAIL_REDUCE(HS_, FULL_) hipLaunchKernelGGL((tail_bwd_reduce_kernel<HS_, FULL_>), dim3(nblk), dim3(256), 0, s, y, scale, shift, mean, invstd, dsr, w, wpart, bnpart, B, H, W)
+  if (sifsr_half_storage()) { if (full) TAIL_REDUCE(true, true); else TAIL_REDUCE(true, false); }
+  else { if (full) TAIL_REDUCE(false, true); else TAIL_REDUCE(false, false); }
+#undef TAIL_REDUCE
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

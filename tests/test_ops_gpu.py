@@ -455,9 +455,12 @@ def test_conv3x3_full_size_grids(L, shape):
 def _bn_setup(L, rs, y, gamma, beta):
     """batch statistics -> (mean, invstd, scale, shift) on the device through sifsr_bn_finalize"""
     B, C, H, W = y.shape
-    t = y.unfold(2, 16, 16).unfold(3, 16, 16)
-    p1 = t.sum((-1, -2)).permute(0, 2, 3, 1).reshape(-1, C)
-    p2 = (t * t).sum((-1, -2)).permute(0, 2, 3, 1).reshape(-1, C)
+    if H % 16 == 0 and W % 16 == 0:
+        t = y.unfold(2, 16, 16).unfold(3, 16, 16)
+        p1 = t.sum((-1, -2)).permute(0, 2, 3, 1).reshape(-1, C)
+        p2 = (t * t).sum((-1, -2)).permute(0, 2, 3, 1).reshape(-1, C)
+    else:                                                  # (unfold would drop the partial tiles: one row per image)
+        p1, p2 = y.double().sum((2, 3)).float(), (y.double() ** 2).sum((2, 3)).float()
     part = dev(torch.stack([p1, p2], -1))
     mean, invstd, scale, shift = (torch.empty(C, device="cuda") for _ in range(4))
     L.call("sifsr_bn_finalize", part, part.shape[0], C, float(B * H * W), dev(gamma), dev(beta), None, None, 0.1, 1e-5,
@@ -465,10 +468,11 @@ def _bn_setup(L, rs, y, gamma, beta):
     return mean, invstd, scale, shift
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 16, 16), (3, 64, 32)])
+@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 16, 16), (3, 64, 32), (2, 24, 40), (1, 19, 37)])
 def test_fused_tail_backward(L, shape):
     """sifsr_conv_out_bn_relu_bwd == autograd of conv_out(relu(bn(y))) w.r.t. (y, gamma, beta, w_out, b_out):
-    the image borders (replicate-padding adjoint) are inside every case, (1,16,16) is one tile with all four."""
+    the image borders (replicate-padding adjoint) are inside every case, (1,16,16) is one tile with all four; the last two
+    shapes end in partial 16x16 tiles (the image border lies inside a tile)."""
     B, H, W = shape
     rs = np.random.RandomState(11 + H)
     y = (rnd(rs, B, 16, H, W) * 1.3 + 0.2).requires_grad_(True)
@@ -482,7 +486,7 @@ def test_fused_tail_backward(L, shape):
     gy, gg, gb, gw, gbias = torch.autograd.grad((out * dsr).sum(), [y, gamma, beta, w, b])
 
     mean, invstd, scale, shift = _bn_setup(L, rs, y.detach(), gamma.detach(), beta.detach())
-    for nblk in (3, B * (H // 16) * (W // 16)):
+    for nblk in (3, B * ((H + 15) // 16) * ((W + 15) // 16)):
         scratch = torch.empty(64 + nblk * (145 + 32), device="cuda")
         dwb = torch.empty(145, device="cuda")
         dgam, dbet = (torch.empty(16, device="cuda") for _ in range(2))
@@ -722,6 +726,78 @@ def test_conv3x3_bwd16_fused_dgrad_wgrad(L, case):
     L.call("sifsr_conv3x3_wgrad_wino", dx, C, dxs, dxsh, None, 0, None, None, g_arg, y_arg, c_arg, C, sc2, 64, dw_s, B, H, W, S())
     torch.cuda.synchronize()
     assert rel_err(gin, gin_s) < 2e-6 and rel_err(dw, dw_s) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(32, 48, 2), (128, 128, 8), (48, 32, 3)])
+def test_conv3x3_bwd16_tail_recomputes_the_outlay_input_gradient(L, shape):
+    """ub3.convbloc.bloc.3 -> outlay: sr = conv_rep(z, w_out), z = relu(bn_train(conv_rep(a, w))).  Given dsr = d loss / d sr the
+    tail entry must return the same (gin, dw, border dL/dy, BatchNorm sums of the layer below) as float64 autograd -- the
+    upstream gradient g = outlay^T(dsr), replicate-padding adjoint included, exists only inside the kernel's staging -- and the
+    same as sifsr_conv3x3_bwd16 fed the float64 g."""
+    H, W, B = shape
+    C = 16
+    rs = np.random.RandomState(4242 + H + W)
+    x = rnd(rs, B, C, H, W)
+    xs = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)); xsh = rnd(rs, C, scale=0.3)
+    w = rnd(rs, C, C, 3, 3, scale=(2.0 / (9 * C)) ** 0.5)
+    w_out = rnd(rs, 1, C, 3, 3, scale=0.2)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)); beta = rnd(rs, C, scale=0.5)
+    dsr = rnd(rs, B, 1, H, W)
+    x64 = x.double()
+    a64 = F.relu(x64 * xs.double().view(1, C, 1, 1) + xsh.double().view(1, C, 1, 1)).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    y64 = conv_rep(a64, w64)
+    z64 = F.relu(F.batch_norm(y64, None, None, gamma.double(), beta.double(), training=True, eps=1e-5))
+    loss = (conv_rep(z64, w_out.double()) * dsr.double()).sum()
+    g64, dy64 = torch.autograd.grad(loss, [z64, y64], retain_graph=True)
+    ga_ref, gw_ref = torch.autograd.grad(loss, [a64, w64])
+    wf = torch.empty(9 * C * C, device="cuda"); wd = torch.empty(4 * 9 * C * C, device="cuda")
+    L.call("sifsr_pack_conv_weights", dev(w), C, C, wf, wd, S())
+    wwf = torch.empty(16 * C * C, device="cuda"); wwd = torch.empty(16 * C * C, device="cuda")
+    L.call("sifsr_pack_conv_weights_wino", dev(w), C, C, wwf, wwd, S())
+    dx, dxs, dxsh = dev(nhwc(x)), dev(xs), dev(xsh)
+    y = torch.empty(B, H, W, C, device="cuda")
+    nblk = L.call("sifsr_conv3x3_stat_blocks", B, H, W, C)
+    part = torch.empty(nblk, C, 2, device="cuda")
+    L.call("sifsr_conv3x3_fwd", dx, C, dxs, dxsh, None, 0, None, None, wf, y, C, part, B, H, W, S())
+    mean, invstd, scale, shift = (torch.empty(C, device="cuda") for _ in range(4))
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    L.call("sifsr_bn_finalize", part, nblk, C, float(B * H * W), dev(gamma), dev(beta), rm, rv, 0.1, 1e-5, mean, invstd, scale, shift, S())
+    npix = B * H * W
+    nb = max(1, min(1024, npix // 256))
+    partials = torch.empty(max(nb, 1024) * C * 2, device="cuda")
+    dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    coef = torch.empty(3 * C, dtype=torch.float64, device="cuda"); coef_f = torch.empty(4 * C, device="cuda")
+    dg = dev(nhwc(g64.float()))
+    L.call("sifsr_bn_relu_bwd_coef", dg, y, scale, shift, mean, invstd, dev(beta), C, npix, partials, nb, dgam, dbet, coef, coef_f, None, H, W, S())
+    rows = L.call("sifsr_conv3x3_bwd16_stat_rows", B, H, W)
+    out = {}
+    for kind in ("tail", "stored_g"):
+        scratch = torch.empty(L.call("sifsr_conv3x3_bwd16_scratch_floats", B, H, W), device="cuda")
+        gin = torch.full((B, H, W, C), float("nan"), device="cuda")
+        dw = torch.full((C, C, 3, 3), float("nan"), device="cuda")
+        border = torch.full((B, H, W, C), float("nan"), device="cuda")
+        bnp = torch.full((rows, C, 2), float("nan"), device="cuda")
+        if kind == "tail":
+            L.call("sifsr_conv3x3_bwd16_tail", dx, dxs, dxsh, dev(dsr.reshape(B, H, W)), dev(w_out), y, coef_f, border, wd, wwd, gin,
+                   dx, dxs, dxsh, bnp, scratch, dw, B, H, W, S())
+        else:
+            L.call("sifsr_conv3x3_bwd16", dx, dxs, dxsh, dg, y, coef_f, border, wd, wwd, gin, None, dx, dxs, dxsh, bnp, scratch, dw,
+                   B, H, W, S())
+        torch.cuda.synchronize()
+        out[kind] = (gin, dw, border, bnp.double().sum(dim=0).cpu())
+    gin, dw, border, s_got = out["tail"]
+    e_gin, e_dw = rel_err(nchw(gin.cpu()), ga_ref), rel_err(dw.cpu(), gw_ref)
+    print(f"bwd16 tail {shape}: gin {e_gin:.2e}, dw {e_dw:.2e}")
+    assert e_gin < TOL and e_dw < TOL
+    edge = torch.zeros(H, W, dtype=torch.bool); edge[0] = edge[-1] = True; edge[:, 0] = edge[:, -1] = True
+    bc = nchw(border.cpu())
+    assert torch.isnan(bc[:, :, ~edge]).all() and rel_err(bc[:, :, edge], dy64[:, :, edge]) < TOL
+    zpos = (x64 * xs.double().view(1, C, 1, 1) + xsh.double().view(1, C, 1, 1)) > 0
+    dz = torch.where(zpos, ga_ref, torch.zeros_like(ga_ref))
+    s_ref = torch.stack((dz.sum(dim=(0, 2, 3)), (dz * x64).sum(dim=(0, 2, 3))), dim=1)
+    assert rel_err(s_got, s_ref) < TOL
+    assert rel_err(gin, out["stored_g"][0]) < 2e-6 and rel_err(dw, out["stored_g"][1]) < 2e-5
 
 
 def test_conv3x3_bwd16_rejects_other_shapes(L):

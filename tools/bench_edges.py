@@ -6,7 +6,7 @@ import sifsr
 from sifsr import _lib as L
 
 B, H, W = 64, 256, 256
-nblk = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+nblk = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 S = lambda: torch.cuda.current_stream().cuda_stream
 g = torch.Generator(device="cuda").manual_seed(0)
 y = torch.randn(B, H, W, 16, device="cuda", generator=g)
