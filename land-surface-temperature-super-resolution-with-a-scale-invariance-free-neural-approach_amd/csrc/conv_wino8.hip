@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 SIFSR_DIAG_CLOCK_DECL   // (diag.h: nothing in the shipped build)
+SIFSR_DIAG_CLOCK8_DECL
 namespace {
 
 constexpr int PW = 18;
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
   __syncthreads();
 
   SIFSR_DIAG_CLOCK_BEGIN
+  SIFSR_DIAG_ACC8_LOCALS
   int buf = 0, q = 0;
   auto do_item = [&](const int j, const int ks) {   // ks = (j + 1) % DEPTH: the register set of item j + 1
     const bool last_q = q + 1 == NQ;
@@ -251,6 +253,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
     // the same time with the matrix pipe idle.  (lds[buf ^ 1] is free since the barrier that closed item j - 1; either way a
     // wave's loads have had one full item to land.)
     const bool stage_first = wave8 >= 4;
+    unsigned long long dt_rd = 0, dt_tr = 0, dt_mm = 0;
+    (void)dt_rd; (void)dt_tr; (void)dt_mm;
+    SIFSR_DIAG_T(c0);
     // staging at the higher wave priority: it is a few dozen instructions that decide when the next loads go out; contraction one
     // step below (still above a co-running weight-gradient kernel at 0).  +0.4 % on the step against the opposite order.
     __builtin_amdgcn_s_setprio(3);
@@ -259,20 +264,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
       issue_loads(ks);          // item j + 1 + DEPTH
     }
     __builtin_amdgcn_s_setprio(2);
+    SIFSR_DIAG_T(c1);
     SIFSR_DIAG_SKIP_MATRIX_WORK(a.B < 0)   // (diag.h: nothing in the shipped build)
 #pragma unroll
     for (int g = 0; g < NGRP; ++g) {
       // ---- the patch's 4x4 input window -> V = B^T d B (in place), as conv_mfma.hip's Winograd consumer
       f32x2 dl[4][4], dh[4][4];
       const float4* Lg = L + lbase + g * 4 * WPITCH;
+      SIFSR_DIAG_T(g0_);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float4 v0 = Lg[r * WPITCH], v1 = Lg[r * WPITCH + WHALF], v2 = Lg[r * WPITCH + 1], v3 = Lg[r * WPITCH + WHALF + 1];
+        // (diag.h SIFSR_DIAG_W8_ABL & 1: one window row read instead of four -- the cost of the window reads)
+        const float4* Lr = (SIFSR_DIAG_W8_ABL & 1) ? Lg : Lg + r * WPITCH;
+        const float4 v0 = Lr[0], v1 = Lr[WHALF], v2 = Lr[1], v3 = Lr[WHALF + 1];
         dl[r][0] = (f32x2){v0.x, v0.y}; dh[r][0] = (f32x2){v0.z, v0.w};
         dl[r][1] = (f32x2){v1.x, v1.y}; dh[r][1] = (f32x2){v1.z, v1.w};
         dl[r][2] = (f32x2){v2.x, v2.y}; dh[r][2] = (f32x2){v2.z, v2.w};
         dl[r][3] = (f32x2){v3.x, v3.y}; dh[r][3] = (f32x2){v3.z, v3.w};
       }
+      SIFSR_DIAG_T(g1_);
+      if (!(SIFSR_DIAG_W8_ABL & 2)) {   // (diag.h: & 2 skips the input transform)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {     // rows: [d0 - d2, d1 + d2, d2 - d1, d1 - d3]
         const f32x2 l0 = pk_sub(dl[0][c], dl[2][c]), l1 = pk_add(dl[1][c], dl[2][c]), l2 = pk_sub(dl[2][c], dl[1][c]), l3 = pk_sub(dl[1][c], dl[3][c]);
@@ -287,9 +298,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
         dl[r][0] = l0; dl[r][1] = l1; dl[r][2] = l2; dl[r][3] = l3;
         dh[r][0] = h0; dh[r][1] = h1; dh[r][2] = h2; dh[r][3] = h3;
       }
+      }
+      SIFSR_DIAG_T(g2_);
       // ---- per xi-row: 16 MFMAs (4 chains), the output transform of the previous row behind them (software-pipelined)
       f32x4 M[2][4];
       auto out_row = [&](const int ar, const f32x4 (&Mr)[4]) {
+        if (SIFSR_DIAG_W8_ABL & 4) { if (ar == 3) { Y[g][0][0] += Mr[0]; Y[g][0][1] += Mr[1]; Y[g][1][0] += Mr[2]; Y[g][1][1] += Mr[3]; } return; }   // (diag.h: & 4: the four xi-rows chained into one accumulator set, one sum at the end)
         // the first reads of fresh MFMA results are plain vector sums: the compiler pads that hazard, not the one of an asm statement
         const f32x4 t0 = Mr[0] + Mr[1] + Mr[2], u = Mr[2] + Mr[3];
         const f32x2 t0l = lo2(t0), t0h = hi2(t0);
@@ -300,12 +314,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
       };
 #pragma unroll
       for (int ar = 0; ar < 4; ++ar) {
-        f32x4 (&Mc)[4] = M[ar & 1];
+        f32x4 (&Mc)[4] = M[(SIFSR_DIAG_W8_ABL & 4) ? 1 : (ar & 1)];
         float4 wr[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) wr[b] = wq[4 * ar + b];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) Mc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[b].x, dl[ar][b][0], zero4, 0, 0, 0);
+        for (int b = 0; b < 4; ++b) Mc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[b].x, dl[ar][b][0], ((SIFSR_DIAG_W8_ABL & 4) && ar > 0) ? Mc[b] : zero4, 0, 0, 0);
 #pragma unroll
         for (int b = 0; b < 4; ++b) Mc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[b].y, dl[ar][b][1], Mc[b], 0, 0, 0);
 #pragma unroll
@@ -320,8 +334,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
         if (ar > 0) out_row(ar - 1, M[(ar - 1) & 1]);
       }
       out_row(3, M[1]);
+      SIFSR_DIAG_T(g3_);
+      SIFSR_DIAG_ADD(dt_rd, g1_ - g0_); SIFSR_DIAG_ADD(dt_tr, g2_ - g1_); SIFSR_DIAG_ADD(dt_mm, g3_ - g2_);
     }
     __builtin_amdgcn_s_setprio(3);
+    SIFSR_DIAG_T(c2);
 
     // ---- item j + 1 -> the other buffer (everybody finished reading it before the previous barrier), item j + 2 in flight
     if (!stage_first && more) {
@@ -361,7 +378,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
         }
       }
     }
+    SIFSR_DIAG_T(c3);
     __syncthreads();   // item j + 1 is staged; lds[buf] may be refilled
+    SIFSR_DIAG_T(c4);
+    SIFSR_DIAG_ACC8(0, (c1 - c0) + (c3 - c2)); SIFSR_DIAG_ACC8(1, dt_rd); SIFSR_DIAG_ACC8(2, dt_tr); SIFSR_DIAG_ACC8(3, dt_mm);
+    SIFSR_DIAG_ACC8(4, c4 - c3); SIFSR_DIAG_ACC8(5, 1);
     buf ^= 1;
     if (last_q) { t = t_next; q = 0; } else ++q;
   };
@@ -372,6 +393,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs a,
   }
 
   SIFSR_DIAG_CLOCK_END(tid)
+  SIFSR_DIAG_ACC8_FLUSH(wave8 >= 4 ? 6 : 0)
   // ---- per-workgroup BatchNorm partials (sum, sum of squares) over all tiles this workgroup produced ----
   if (a.stat_partials != nullptr) {
     const int px = lane & 15;

@@ -10,6 +10,12 @@
 //   -DSIFSR_PK_MODE=0..3   form of the packed add / subtract of the Winograd transforms (common.h; 0 ships)
 #pragma once
 
+//   -DSIFSR_DIAG_W8_ABL=n  conv3x3_wino8_kernel with parts of its non-matrix work removed (wrong results; what each part costs):
+//                          1 one window row read instead of four, 2 no input transform, 4 a quarter of the output transform
+#ifndef SIFSR_DIAG_W8_ABL
+#define SIFSR_DIAG_W8_ABL 0
+#endif
+
 #ifdef SIFSR_DIAG_NOMFMA
 #define SIFSR_DIAG_SKIP_MATRIX_WORK(never_true) if (never_true)
 #else
@@ -40,6 +46,22 @@
     if (reset) { unsigned long long z[10] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sifsr_clk16), z, 80) != hipSuccess) return 2; } \
     return 0;                                                                                                             \
   }
+// conv3x3_wino8_kernel: per item and wave team (waves 0 and 4 report; [0..5] the contract-first team, [6..11] the stage-first one):
+//   staging, window reads (incl. the wait for them), input transform, MFMAs + output transform, epilogue + barrier wait, item count
+#define SIFSR_DIAG_CLOCK8_DECL                                                                                              \
+  __device__ unsigned long long sifsr_clk8[12];                                                                           \
+  extern "C" __attribute__((visibility("default"))) int sifsr_debug_timers8(unsigned long long* out12, int reset) {       \
+    if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(sifsr_clk8), 96) != hipSuccess) return 1;                                   \
+    if (reset) { unsigned long long z[12] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sifsr_clk8), z, 96) != hipSuccess) return 2; } \
+    return 0;                                                                                                             \
+  }
+#define SIFSR_DIAG_ACC8_LOCALS unsigned long long dacc8__[6] = {0, 0, 0, 0, 0, 0};
+#define SIFSR_DIAG_ACC8(i, d) dacc8__[(i)] += (unsigned long long)(d)   /* registers; one atomic per counter at the end of the kernel */
+#define SIFSR_DIAG_ACC8_FLUSH(ro)                                                                          \
+  if (lane == 0 && (wave8 & 3) == 0) {                                                                     \
+    for (int i__ = 0; i__ < 6; ++i__) atomicAdd(&sifsr_clk8[(ro) + i__], dacc8__[i__]);                    \
+  }
+#define SIFSR_DIAG_ADD(var, d) var += (d)
 #define SIFSR_DIAG_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define SIFSR_DIAG_ACC16(i, d) do { if (lane == 0 && wave == 0) atomicAdd(&sifsr_clk16[(i)], (unsigned long long)(d)); } while (0)
 #define SIFSR_DIAG_WAIT_LOADS(var)                                   \
@@ -55,6 +77,11 @@
 #define SIFSR_DIAG_CLOCK_END(tid)
 #define SIFSR_DIAG_CLOCK_READER
 #define SIFSR_DIAG_CLOCK16_DECL
+#define SIFSR_DIAG_CLOCK8_DECL
+#define SIFSR_DIAG_ACC8_LOCALS
+#define SIFSR_DIAG_ACC8(i, d)
+#define SIFSR_DIAG_ACC8_FLUSH(ro)
+#define SIFSR_DIAG_ADD(var, d)
 #define SIFSR_DIAG_T(var)
 #define SIFSR_DIAG_ACC16(i, d)
 #define SIFSR_DIAG_WAIT_LOADS(var)

@@ -12,7 +12,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAVOURS = [
     ("conv_mfma.hip", "-DSIFSR_DIAG_NOMFMA"), ("conv_wino8.hip", "-DSIFSR_DIAG_NOMFMA"), ("conv_wgrad_wino.hip", "-DSIFSR_DIAG_NOMFMA"),
     ("conv_bwd16.hip", "-DSIFSR_DIAG_NOMFMA"),
-    ("conv_wino8.hip", "-DSIFSR_DIAG_CLOCK"), ("conv_bwd16.hip", "-DSIFSR_DIAG_CLOCK"),
+    ("conv_wino8.hip", "-DSIFSR_DIAG_CLOCK"), ("conv_bwd16.hip", "-DSIFSR_DIAG_CLOCK"), ("conv_wino8.hip", "-DSIFSR_DIAG_W8_ABL=7"),
     ("conv_wino8.hip", "-DSIFSR_PK_MODE=1"), ("conv_wgrad_wino.hip", "-DSIFSR_PK_MODE=2"), ("conv_bwd16.hip", "-DSIFSR_PK_MODE=3"),
 ]
 
