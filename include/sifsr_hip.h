@@ -38,7 +38,8 @@ SIFSR_API int sifsr_layer_table(int* out, int capacity_rows);
 /* ---- ModelB_2 (model.py:533-645) ------------------------------------------------------------ */
 SIFSR_API size_t sifsr_model_workspace_bytes(int B, int H, int W, int training);
 /* Debug/test introspection: float offsets of the named workspace regions, in this order:
- * y[17] (raw conv outputs, NHWC), P[3], R[3], U[3], g[17] (dL/d relu(bn(y)); dL/dy is not stored), dyB[3] (unused), gP[3], gU[3],
+ * y[17] (raw conv outputs, NHWC), P[3], R[3], U[3], g[17] (dL/d relu(bn(y)); dL/dy is not stored; g[0] leaves the backward multiplied
+ * by its ReLU mask where the first layer's weight gradient runs in its linear form), dyB[3] (unused), gP[3], gU[3],
  * mean, invstd, scale, shift (per-channel vectors of all layers, indexed by ch_off).  Returns the count (56). */
 SIFSR_API int sifsr_model_workspace_regions(int B, int H, int W, size_t* out, int capacity);
 /* ModelB_2.forward, model.py:608-645.  training != 0: batch statistics, running-stat update
@@ -204,6 +205,15 @@ SIFSR_API int sifsr_conv_in_bn_relu_bwd(const float* x, const float* g, const fl
                                         const float* shift, const float* mean, const float* invstd, float* scratch,
                                         int nblk, float* dw, float* dgamma, float* dbeta, double* coef, int B, int H, int W,
                                         void* stream);
+/* The weight gradient of inbloc.bloc.0 (Conv2d(2, 16, 3, bias=False) + BatchNorm + ReLU, model.py:596) WITHOUT reading (g, y): what
+ * ModelB_2's backward runs since round 3 where the fused 16 -> 16 kernel serves inbloc.bloc.3.  dL/dy = sd*dz + k1*y + k0 is affine in
+ * dz = g*[y*scale+shift > 0] and y = W p (p = the 18 replicate-padded inputs under a pixel), so
+ *   dW = sd * D + k1 * (W G) + k0 * X,   D = sum dz p^T (one read of dz),  G = sum p p^T and X = sum p (functions of x alone).
+ * x (B,2,H,W) NCHW; dz (B,H,W,16) NHWC (bf16 after sifsr_set_op_storage_bf16(1)); w (16,2,3,3); coef = the 48 float64
+ * [sd | k1 | k0] that sifsr_conv_in_bn_relu_bwd / sifsr_bn_relu_bwd_coef return; scratch: _scratch_floats(nblk) floats; dw (16,2,3,3). */
+SIFSR_API size_t sifsr_conv_in_bwd_linear_scratch_floats(int nblk);
+SIFSR_API int sifsr_conv_in_bwd_linear(const float* x, const float* dz, const float* w, const double* coef, float* scratch,
+                                       int nblk, float* dw, int B, int H, int W, void* stream);
 
 /* ---- BatchNorm2d (model.py:136,139,508; eps 1e-5, momentum 0.1) ------------------------------ */
 SIFSR_API int sifsr_bn_finalize(const float* stat_partials, int nblk, int C, double count, const float* gamma,

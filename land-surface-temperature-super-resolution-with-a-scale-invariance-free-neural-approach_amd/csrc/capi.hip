@@ -384,6 +384,19 @@ int sifsr_conv_out_bn_relu_bwd(const float* y, const float* scale, const float* 
   if (rc) return rc;
   return launch_tail_bwd_apply(y, scale, shift, coef, dsr, w, dy, B, H, W, S(stream));
 }
+// the same weight gradient from dz = g * [y*scale+shift > 0] and the BatchNorm-backward coefficients alone (edge_conv.hip, "head"):
+// dW = sd * D + k1 * (W G) + k0 * X with D = sum dz p^T, G = sum p p^T, X = sum p over the input patches p
+size_t sifsr_conv_in_bwd_linear_scratch_floats(int nblk) { return conv_in_gram_scratch_floats() + (size_t)(nblk > 0 ? nblk : 0) * 288; }
+int sifsr_conv_in_bwd_linear(const float* x, const float* dz, const float* w, const double* coef, float* scratch, int nblk,
+                             float* dw, int B, int H, int W, void* stream) {
+  if (!x || !dz || !w || !coef || !scratch || !dw || nblk < 1) return SIFSR_ERR_ARG;
+  float* part = scratch + conv_in_gram_scratch_floats();
+  int rc = launch_conv_in_gram(x, scratch, B, H, W, S(stream));
+  if (rc) return rc;
+  rc = launch_conv_in_dz_wgrad(x, dz, part, nblk, B, H, W, S(stream));
+  if (rc) return rc;
+  return launch_conv_in_dw_combine(part, nblk, conv_in_gram_result(scratch), w, coef, dw, S(stream));
+}
 int sifsr_conv_in_bn_relu_bwd(const float* x, const float* g, const float* y, const float* scale, const float* shift,
                               const float* mean, const float* invstd, float* scratch, int nblk, float* dw, float* dgamma,
                               float* dbeta, double* coef, int B, int H, int W, void* stream) {

@@ -112,6 +112,9 @@ struct Bwd16Args {
   float* slabs;                    // out: conv3x3_bwd16_grid() weight-gradient slabs of 16 * 256 floats (Winograd domain,
                                    //   the layout of conv_wgrad_wino.hip; reduce with launch_wgrad_wino_finish, nblk = grid)
   int B, H, W;
+  int store_dz = 0;                // with stat_partials: gin is stored MASKED, dz = gin * [bn_y * scale + shift > 0] -- what the layer below's
+                                   //   BatchNorm backward consumes; for a layer below whose only other consumer is the linear form of its
+                                   //   weight gradient (inbloc.bloc.0: edge_conv.hip conv_in_dz_wgrad_kernel)
   int half = 0;                    // 1: the activation tensors above are stored as bf16 (the bf16 compute mode; the arithmetic stays
                                    //    fp32 -- fp32 MFMAs in the Winograd domain: these layers are HBM-bound, what counts is the bytes)
 };
@@ -124,7 +127,7 @@ int launch_conv3x3_bwd16(const Bwd16Args& a, hipStream_t s);
 int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, int Cin, float* g0, int C0,
                             int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s, int bf16 = 0,
                             const float* bn_y = nullptr, const float* bn_scale = nullptr, const float* bn_shift = nullptr,
-                            float* bn_partials = nullptr);
+                            float* bn_partials = nullptr, int masked = 0);   // masked: g0 holds g * [bn_y*scale+shift > 0] (with bn_partials)
 int dgrad_border_waves(int B, int H, int W, int Cin);   // rows of bn_partials ([wave][16][2]) the border kernel writes
 
 // wwf / wwd (optional): Winograd-domain packs of all layers, 16/9 of the size and offsets of wfwd

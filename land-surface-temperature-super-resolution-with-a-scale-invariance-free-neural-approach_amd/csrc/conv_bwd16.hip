@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
           const float4 vr = round_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
           v = (f32x4){vr.x, vr.y, vr.z, vr.w};
         }
-        as4<HS>(rd, pixo, 0u, make_float4(v[0], v[1], v[2], v[3]));
+        if (!(bn_stats && a.store_dz)) as4<HS>(rd, pixo, 0u, make_float4(v[0], v[1], v[2], v[3]));
         if (bn_stats) {   // dz = g_in * [y_below * scale + shift > 0]; sum dz, sum dz * y_below.  y_below = the staged x tile (raw) in LDS:
           // channel 4 kq + r lives in plane kq + 4 r, pixel (row + 1, column + 1) of the halo.  (Round 3: these were four global
           // loads per lane requested before the MFMAs -- under this kernel's memory load they came back after the contraction
@@ -406,11 +406,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
           const float* yp_ = xp[buf] + kq * XPS + (g0 + 2 * pyl + oy + 1) * XPW + 2 * pxp + ox + 1;
           const float yy4[4] = {yp_[0], yp_[4 * XPS], yp_[8 * XPS], yp_[12 * XPS]};
           const float scv[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, shv[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
+          float dzv[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float dz = fmaf(yy4[r], scv[r], shv[r]) > 0.f ? v[r] : 0.f;
+            dzv[r] = dz;
             s1[r] += dz; s2[r] = fmaf(dz, yy4[r], s2[r]);
           }
+          if (a.store_dz) as4<HS>(rd, pixo, 0u, make_float4(dzv[0], dzv[1], dzv[2], dzv[3]));
         }
       }
     });
@@ -537,6 +540,7 @@ int launch_conv3x3_bwd16(const Bwd16Args& a, hipStream_t s) {
   if (a.stat_partials != nullptr && (!a.bn_y || !a.bn_scale || !a.bn_shift)) return SIFSR_ERR_ARG;
   // the BatchNorm sums are taken from the staged input tile: the layer below IS the layer whose raw output is the input
   if (a.stat_partials != nullptr && (a.bn_y != a.x || a.bn_scale != a.x_scale || a.bn_shift != a.x_shift)) return SIFSR_ERR_ARG;
+  if (a.store_dz && (a.stat_partials == nullptr || a.addend != nullptr)) return SIFSR_ERR_ARG;
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
   auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
   const int tx_ = a.W / 16, ty_ = a.H / 16, ntiles = a.B * tx_ * ty_;

@@ -850,7 +850,7 @@ __global__ __launch_bounds__(256, 8) void dgrad_border_kernel(const float* __res
                                                            int bf16, const float* __restrict__ bn_y,
                                                            const float* __restrict__ bn_scale,
                                                            const float* __restrict__ bn_shift,
-                                                           float* __restrict__ bn_partials) {
+                                                           float* __restrict__ bn_partials, int masked) {
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int NBI = Cin / 16, NQ = Cout / 16;
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256, 8) void dgrad_border_kernel(const float* __res
       }
     }
   }
-  if (valid) {
+  if (valid && !masked) {
     // D rows = ci 4*kq + r, col = pixel  ->  one float4 read-modify-write per lane (read issued at the top)
     float4 v = g_old;
     v.x += acc[0]; v.y += acc[1]; v.z += acc[2]; v.w += acc[3];
@@ -973,6 +973,10 @@ __global__ __launch_bounds__(256, 8) void dgrad_border_kernel(const float* __res
       for (int r = 0; r < 4; ++r) {
         const float dz = fmaf(yy[r], scv[r], shv[r]) > 0.f ? acc[r] : 0.f;
         d1[r] = dz; d2[r] = dz * yy[r];
+      }
+      if (masked) {   // the main kernel stored dz = g * [z > 0] instead of g (conv_bwd16.hip, store_dz): the fold adds its masked part
+        const float4 v = make_float4(g_old.x + d1[0], g_old.y + d1[1], g_old.z + d1[2], g_old.w + d1[3]);
+        if (bf16) stA4<true>(dbase, de, v); else stA4<false>(dbase, de, v);
       }
     }
 #pragma unroll
@@ -1148,12 +1152,13 @@ int dgrad_border_waves(int B, int H, int W, int Cin) {
 
 int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, int Cin, float* g0, int C0,
                             int split_ch, float* g1, int C1, int B, int H, int W, hipStream_t s, int bf16,
-                            const float* bn_y, const float* bn_scale, const float* bn_shift, float* bn_partials) {
+                            const float* bn_y, const float* bn_scale, const float* bn_shift, float* bn_partials, int masked) {
   if (bn_partials != nullptr && (Cin != 16 || !bn_y || !bn_scale || !bn_shift)) return SIFSR_ERR_ARG;
+  if (masked && bn_partials == nullptr) return SIFSR_ERR_ARG;
   if (H < 3 || W < 2 || Cin % 16 || Cout % 16) return SIFSR_ERR_SHAPE;
   const int waves = B * (2 * ((W + 15) / 16) + 2 * ((H - 2 + 15) / 16)) * (Cin / 16);
   hipLaunchKernelGGL(dgrad_border_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, dy, Cout, wdg_layer, Cin, g0, C0,
-                     split_ch, g1, C1, B, H, W, bf16, bn_y, bn_scale, bn_shift, bn_partials);
+                     split_ch, g1, C1, B, H, W, bf16, bn_y, bn_scale, bn_shift, bn_partials, masked);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

@@ -14,6 +14,13 @@ int launch_conv_out_wgrad(const float* y, const float* scale, const float* shift
                           int nblk, float* dw, float* db, int B, int H, int W, hipStream_t s);
 int launch_conv_in_wgrad_fused(const float* x, const float* g, const float* y, const float* scale, const float* shift,
                                const double* coef, float* partials, int nblk, float* dw, int B, int H, int W, hipStream_t s);
+// "head" without a second read of (g, y): dW = sd * D + k1 * (W G) + k0 * X (edge_conv.hip); gram scratch holds G | X as float64
+size_t conv_in_gram_scratch_floats();
+int launch_conv_in_gram(const float* x, float* scratch, int B, int H, int W, hipStream_t s);
+const double* conv_in_gram_result(const float* scratch);
+int launch_conv_in_dz_wgrad(const float* x, const float* dz, float* partials, int nblk, int B, int H, int W, hipStream_t s);
+int launch_conv_in_dw_combine(const float* partials, int nblk, const double* gram, const float* w, const double* coef, float* dw,
+                              hipStream_t s);
 // ---- fused_edges.hip ---- (outlay backward + BatchNorm/ReLU backward of its producer)
 int launch_tail_bwd_reduce(const float* y, const float* scale, const float* shift, const float* mean, const float* invstd,
                            const float* dsr, const float* w, float* wpart, float* bnpart, int nblk, int B, int H, int W,

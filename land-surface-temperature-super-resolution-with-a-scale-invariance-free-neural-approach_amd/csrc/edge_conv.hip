@@ -330,6 +330,247 @@ __global__ __launch_bounds__(256) void conv_out_wgrad_kernel(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// input conv weight gradient WITHOUT reading (g, y) again ("head", round 3).  dL/dy of inbloc.bloc.0 is affine in dz = g*[z>0] and y,
+//   dy = sd*dz + k1*y + k0  (per channel; BatchNorm + ReLU backward, model.py:136-137),  and y = W p (Conv2d(2, 16, 3, bias=False)),
+// p(q) = the 18 replicate-padded input values under pixel q.  So
+//   dW[c][k] = sum_q dy[q][c] p(q)[k] = sd[c] * D[c][k] + k1[c] * (W G)[c][k] + k0[c] * X[k]
+//   D = sum_q dz[q] p(q)^T   (16 x 18: the only part that needs a gradient tensor -- ONE 16-channel read, of dz, which the
+//                             input-gradient kernel of inbloc.bloc.3 stores in place of g: it has the mask in its epilogue)
+//   G = sum_q p(q) p(q)^T    (18 x 18 Gram matrix of the input patches),  X = sum_q p(q):  functions of the network INPUT alone,
+//                             computed on the second stream while the backward chain runs.
+// The fused form (conv_in_wgrad_kernel<FUSED>) reads g and y = 2 tensors of 16 channels at full resolution for a 2 -> 16 layer.
+// ------------------------------------------------------------------------------------------
+constexpr int GRAM_N = 189, GRAM_PITCH = 192;            // 171 upper-triangle entries of G (row-major, k >= k') + 18 of X
+__host__ __device__ constexpr int gram_idx(int kr, int k) { return kr * 18 - kr * (kr - 1) / 2 + (k - kr); }
+
+// row kr of the upper triangle = entries (kr, kr .. 17), as packed pairs (k, k + 1) from k = kr (pv[18] = pv[19] = 0 pad an odd row)
+template <int WV> static __device__ __forceinline__ void gram_rows(const float (&pv)[20], f32x2 (&acc)[26]) {
+  int n = 0;
+#pragma unroll
+  for (int kr = WV; kr < 18; kr += 4)
+#pragma unroll
+    for (int k = kr; k < 18; k += 2) { acc[n] = __builtin_elementwise_fma((f32x2){pv[kr], pv[kr]}, (f32x2){pv[k], pv[k + 1]}, acc[n]); ++n; }
+}
+template <int WV> static __device__ __forceinline__ void gram_store(const f32x2 (&acc)[26], float* __restrict__ row, int lane) {
+  int n = 0;
+#pragma unroll
+  for (int kr = WV; kr < 18; kr += 4)
+#pragma unroll
+    for (int k = kr; k < 18; k += 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float v = acc[n][h];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+        if (lane == 0 && k + h < 18) row[gram_idx(kr, k + h)] = v;
+      }
+      ++n;
+    }
+}
+
+// persistent workgroups over 16x16 tiles; wave w accumulates the rows k' = w, w + 4, ... of the upper triangle for all 256 pixels
+// of the tile (4 per lane), wave 3 (the shortest rows) also X.  partials: [gridDim.x][GRAM_PITCH]
+template <bool FULL>   // FULL: H and W are multiples of 16 (no partial tiles)
+__global__ __launch_bounds__(256, 2) void conv_in_gram_kernel(const float* __restrict__ x, float* __restrict__ partials, int B, int H, int W) {
+  __shared__ float tile[2][2 * 324 + 8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16, ntiles = B * tiles_x * tiles_y;
+  // the next tile's halo planes travel through registers (3 values per thread): the loads are in flight while this tile is processed
+  float px_[3];
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+    const int x0 = tx * 16, y0 = ty * 16;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = min(tid + 256 * i, 2 * 324 - 1);
+      const int c = e / 324, p = e - c * 324;
+      const int py = p / 18, pxx = p - py * 18;
+      px_[i] = x[((size_t)(b * 2 + c) * H + clampi(y0 - 1 + py, 0, H - 1)) * W + clampi(x0 - 1 + pxx, 0, W - 1)];
+    }
+  };
+  f32x2 acc[26], xs[9];
+#pragma unroll
+  for (int i = 0; i < 26; ++i) acc[i] = (f32x2){0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) xs[i] = (f32x2){0.f, 0.f};
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  int buf = 0;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x, buf ^= 1) {
+    tile[buf][tid] = px_[0];
+    tile[buf][tid + 256] = px_[1];
+    if (tid + 512 < 2 * 324) tile[buf][tid + 512] = px_[2];
+    __syncthreads();          // one barrier per tile (the other buffer was last read before the previous one)
+    fetch(t + (int)gridDim.x < ntiles ? t + (int)gridDim.x : t);
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
+    const int x0 = tx * 16, y0 = ty * 16;
+    const float* T = tile[buf];
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      const int r = (lane >> 4) + 4 * i, col = lane & 15;
+      const bool inside = FULL || (y0 + r < H && x0 + col < W);    // partial tiles: pixels past the image contribute nothing
+      float pv[20];
+#pragma unroll
+      for (int k = 0; k < 18; ++k) {
+        const float v = T[(k / 9) * 324 + (r + (k % 9) / 3) * 18 + col + (k % 9) % 3];
+        pv[k] = inside ? v : 0.f;
+      }
+      pv[18] = pv[19] = 0.f;
+      switch (wave) {
+        case 0: gram_rows<0>(pv, acc); break;
+        case 1: gram_rows<1>(pv, acc); break;
+        case 2: gram_rows<2>(pv, acc); break;
+        default:
+          gram_rows<3>(pv, acc);
+#pragma unroll
+          for (int k = 0; k < 9; ++k) xs[k] += (f32x2){pv[2 * k], pv[2 * k + 1]};
+      }
+    }
+  }
+  float* row = partials + (size_t)blockIdx.x * GRAM_PITCH;
+  switch (wave) {
+    case 0: gram_store<0>(acc, row, lane); break;
+    case 1: gram_store<1>(acc, row, lane); break;
+    case 2: gram_store<2>(acc, row, lane); break;
+    default:
+      gram_store<3>(acc, row, lane);
+#pragma unroll
+      for (int k = 0; k < 18; ++k) {
+        float v = xs[k >> 1][k & 1];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+        if (lane == 0) row[171 + k] = v;
+      }
+  }
+}
+
+// gram[e] = sum over the workgroup rows, float64, fixed order: one 64-thread workgroup per entry
+__global__ __launch_bounds__(64) void conv_in_gram_reduce_kernel(const float* __restrict__ partials, int nblk, double* __restrict__ gram) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0;
+  for (int k = lane; k < nblk; k += 64) s += (double)partials[(size_t)k * GRAM_PITCH + e];
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+  if (lane == 0) gram[e] = s;
+}
+
+// D partials: work item = (pixel, channel quad), dz as one coalesced float4 straight from HBM, the pixel's 18 patch values from the
+// LDS halo planes of x; 72 FMAs (36 packed) per item into per-lane accumulators.  Persistent, next tile's dz quads and x halo
+// in flight (as tail_bwd_reduce_kernel, fused_edges.hip).  partials: [gridDim.x][288], e = co * 18 + ci * 9 + t
+template <bool HS>   // HS: dz stored as bf16
+__global__ __launch_bounds__(256, 3) void conv_in_dz_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                                  float* __restrict__ partials, int B, int H, int W) {
+  SIFSR_CHAIN_PRIO();
+  __shared__ float tile[2][2 * 324 + 8];
+  __shared__ float red[4][4][72];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16, ntiles = B * tiles_x * tiles_y;
+  const int c4 = tid & 3, pl = tid >> 2;
+  const int lx = pl & 15, ly0 = pl >> 4;
+  f32x2 acc[4][9];                                       // D[4 c4 + j][2 u, 2 u + 1]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int u = 0; u < 9; ++u) acc[j][u] = (f32x2){0.f, 0.f};
+  float4 pz[4];
+  float px_[3];
+  size_t nbase = 0;
+  int nrow[4] = {0, 0, 0, 0};
+  bool nin[4] = {false, false, false, false};
+  auto fetch_z = [&](int k) __attribute__((always_inline)) { pz[k] = ldA4<HS>(dz, nbase + (size_t)nrow[k]); };
+  auto fetch = [&](int tl) __attribute__((always_inline)) {
+    const int tx = tl % tiles_x, r = tl / tiles_x, ty = r % tiles_y, b = r / tiles_y;
+    const int x0 = tx * 16, y0 = ty * 16;
+    const int gx = min(x0 + lx, W - 1);
+    nbase = ((size_t)(b * H) * W + gx) * 16 + 4 * c4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      nrow[k] = min(y0 + ly0 + 4 * k, H - 1) * W * 16;
+      nin[k] = y0 + ly0 + 4 * k < H && x0 + lx < W;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = min(tid + 256 * i, 2 * 324 - 1);
+      const int c = e / 324, p = e - c * 324;
+      const int py = p / 18, pxx = p - py * 18;
+      px_[i] = x[((size_t)(b * 2 + c) * H + clampi(y0 - 1 + py, 0, H - 1)) * W + clampi(x0 - 1 + pxx, 0, W - 1)];
+    }
+  };
+  int buf = 0;
+  bool cin_[4] = {false, false, false, false};
+  if ((int)blockIdx.x < ntiles) {
+    fetch(blockIdx.x);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fetch_z(k);
+  }
+  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x, buf ^= 1) {
+    tile[buf][tid] = px_[0];
+    tile[buf][tid + 256] = px_[1];
+    if (tid + 512 < 2 * 324) tile[buf][tid + 512] = px_[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cin_[k] = nin[k];
+    __syncthreads();          // one barrier per tile (the other buffer was last read before the previous one)
+    fetch(tl + (int)gridDim.x < ntiles ? tl + (int)gridDim.x : tl);
+    const float* T = tile[buf];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float4 zv = pz[k];
+      fetch_z(k);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!cin_[k]) zv = make_float4(0.f, 0.f, 0.f, 0.f);   // partial tiles
+      const int ly = ly0 + 4 * k;
+      f32x2 pp[9];                                         // the 18 patch values as pairs (n, n + 1), n = ci * 9 + t
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        const int n0 = 2 * u, n1 = 2 * u + 1;
+        pp[u] = (f32x2){T[(n0 / 9) * 324 + (ly + (n0 % 9) / 3) * 18 + lx + (n0 % 9) % 3],
+                        T[(n1 / 9) * 324 + (ly + (n1 % 9) / 3) * 18 + lx + (n1 % 9) % 3]};
+      }
+      const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 9; ++u) acc[j][u] = __builtin_elementwise_fma((f32x2){zz[j], zz[j]}, pp[u], acc[j][u]);
+    }
+  }
+  // across the 16 lanes of a channel quad, then the 4 waves (fp32: a workgroup sums a few thousand terms; float64 across workgroups)
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int u = 0; u < 9; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float v = acc[j][u][h];
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1) v += __shfl_xor(v, m);
+        if (lane < 4) red[wave][c4][j * 18 + 2 * u + h] = v;
+      }
+  __syncthreads();
+  for (int e = tid; e < 288; e += 256) {
+    const int co = e / 18, n = e - co * 18;
+    const int q = co >> 2, i = (co & 3) * 18 + n;
+    partials[(size_t)blockIdx.x * 288 + e] = red[0][q][i] + red[1][q][i] + red[2][q][i] + red[3][q][i];
+  }
+}
+
+// dW[c][k] = sd[c] * D[c][k] + k1[c] * (W G)[c][k] + k0[c] * X[k], float64; one 64-thread workgroup per entry e = c * 18 + k
+__global__ __launch_bounds__(64) void conv_in_dw_combine_kernel(const float* __restrict__ partials, int nblk,
+                                                                const double* __restrict__ gram, const float* __restrict__ w,
+                                                                const double* __restrict__ coef, float* __restrict__ dw) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const int c = e / 18, k = e - c * 18;
+  double s = 0.0;
+  for (int r = lane; r < nblk; r += 64) s += (double)partials[(size_t)r * 288 + e];
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+  if (lane == 0) {
+    double a = 0.0;
+    for (int kr = 0; kr < 18; ++kr) a += (double)w[c * 18 + kr] * gram[kr <= k ? gram_idx(kr, k) : gram_idx(k, kr)];
+    dw[e] = (float)(coef[c] * s + coef[16 + c] * a + coef[32 + c] * gram[171 + k]);
+  }
+}
+
 // out[e] = sum_k partials[k][e] in float64, fixed order (deterministic): 4 outputs x 64 row lanes per block
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partials, int nblk, int n,
                                                            float* __restrict__ out) {
@@ -380,6 +621,35 @@ int launch_conv_in_wgrad_fused(const float* x, const float* g, const float* y, c
   if (sifsr_half_storage()) hipLaunchKernelGGL((conv_in_wgrad_kernel<true, true>), dim3(nblk), dim3(256), 0, s, x, g, y, scale, shift, coef, partials, B, H, W);
   else hipLaunchKernelGGL((conv_in_wgrad_kernel<true, false>), dim3(nblk), dim3(256), 0, s, x, g, y, scale, shift, coef, partials, B, H, W);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(72), dim3(256), 0, s, partials, nblk, 288, dw);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+
+size_t conv_in_gram_scratch_floats() { return (size_t)1024 * GRAM_PITCH + 2 * GRAM_PITCH; }
+// scratch (conv_in_gram_scratch_floats() floats): [1024][192] partial rows, then 189 float64 = the result (G upper triangle | X)
+int launch_conv_in_gram(const float* x, float* scratch, int B, int H, int W, hipStream_t s) {
+  if (H < 1 || W < 1 || B < 1) return SIFSR_ERR_SHAPE;
+  const int ntiles = B * ((H + 15) / 16) * ((W + 15) / 16);
+  const int nblk = ntiles < 512 ? ntiles : 512;   // two workgroups per CU are resident (registers): one round
+  if (H % 16 == 0 && W % 16 == 0) hipLaunchKernelGGL(conv_in_gram_kernel<true>, dim3(nblk), dim3(256), 0, s, x, scratch, B, H, W);
+  else hipLaunchKernelGGL(conv_in_gram_kernel<false>, dim3(nblk), dim3(256), 0, s, x, scratch, B, H, W);
+  hipLaunchKernelGGL(conv_in_gram_reduce_kernel, dim3(GRAM_N), dim3(64), 0, s, scratch, nblk, reinterpret_cast<double*>(scratch + (size_t)1024 * GRAM_PITCH));
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+const double* conv_in_gram_result(const float* scratch) { return reinterpret_cast<const double*>(scratch + (size_t)1024 * GRAM_PITCH); }
+
+// D partials from the stored dz (nblk workgroups; three per CU are resident: nblk <= 768 keeps it to one round)
+int launch_conv_in_dz_wgrad(const float* x, const float* dz, float* partials, int nblk, int B, int H, int W, hipStream_t s) {
+  if (H < 1 || W < 1 || nblk < 1) return SIFSR_ERR_SHAPE;
+  if (sifsr_half_storage()) hipLaunchKernelGGL(conv_in_dz_wgrad_kernel<true>, dim3(nblk), dim3(256), 0, s, x, dz, partials, B, H, W);
+  else hipLaunchKernelGGL(conv_in_dz_wgrad_kernel<false>, dim3(nblk), dim3(256), 0, s, x, dz, partials, B, H, W);
+  SIFSR_LAUNCH_CHECK();
+  return SIFSR_OK;
+}
+int launch_conv_in_dw_combine(const float* partials, int nblk, const double* gram, const float* w, const double* coef, float* dw,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(conv_in_dw_combine_kernel, dim3(288), dim3(64), 0, s, partials, nblk, gram, w, coef, dw);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

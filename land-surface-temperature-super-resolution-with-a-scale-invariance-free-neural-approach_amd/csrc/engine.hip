@@ -132,6 +132,7 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
     for (int k = 0; k < 3; ++k) w.gP[k] = take(pc[k] * N[k + 1]);
     w.gU[0] = take(64 * N[2]); w.gU[1] = take(32 * N[1]); w.gU[2] = take(16 * N[0]);
     w.slabs = take(1024 * 288);   // edge-layer partials
+    w.gram = take(conv_in_gram_scratch_floats());
     w.slab_l[0] = 0; w.slab_cap[0] = 0;
     size_t wino_pairs = 0;
     for (int l = 1; l < SIFSR_NUM_BN_LAYERS; ++l) {
@@ -207,6 +208,7 @@ struct SideLane {
   hipStream_t s = nullptr;
   hipEvent_t ev[SIFSR_NUM_BN_LAYERS] = {};
   hipEvent_t join = nullptr;
+  hipEvent_t aux = nullptr;    // side -> main hand-off that is not the final join (the first layer's Gram matrix)
   bool ok = false;
   std::mutex in_use;   // held for a whole backward enqueue: two host threads of one device never interleave on ev[]
 };
@@ -241,6 +243,7 @@ SideLane* side_lane(hipStream_t main_stream) {
     bool ok = hipStreamCreateWithPriority(&L.s, hipStreamNonBlocking, lo) == hipSuccess;
     for (int i = 0; ok && i < SIFSR_NUM_BN_LAYERS; ++i) ok = hipEventCreateWithFlags(&L.ev[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&L.join, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&L.aux, hipEventDisableTiming) == hipSuccess;
     L.ok = ok;
     (void)hipGetLastError();
   }
@@ -479,7 +482,7 @@ bool bwd16_usable(const Ctx& c, int l, ConvSrc s0) {
 // dy_mode 0: `dy` is dL/dy itself.  1: `dy` is g = dL/d relu(bn(y_l)), dL/dy formed while staging.  2 (l = ub3.convbloc.bloc.3): `dy` is
 // d loss / d sr and g the input gradient of outlay, recomputed while staging (no tail_bwd_apply pass).
 int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin, const float* addend, int bn_layer, int* stat_rows,
-                    int dy_mode, bool* applied) {
+                    int dy_mode, bool* applied, bool store_dz = false) {
   const LayerInfo& L = c.nt.L[l];
   *applied = false;
   if (stat_rows) *stat_rows = 0;
@@ -503,6 +506,8 @@ int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin
   a.slabs = c.f(c.lay.slab_l[l]);
   a.B = c.B; a.H = lh; a.W = lw;
   a.half = c.bf16;
+  if (store_dz && !fuse) return SIFSR_ERR_ARG;
+  a.store_dz = store_dz ? 1 : 0;   // gin leaves the kernel (and the border fold) multiplied by the ReLU mask of the layer below
   {
     ProfScope ps(l, 2, c.s);     // one launch = both passes of the layer: timed as its input-gradient selection
     SIFSR_TRY(launch_conv3x3_bwd16(a, c.s));
@@ -510,7 +515,7 @@ int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin
   const float* wdg_f32 = c.f(c.lay.wdg) + 4 * (size_t)L.wpack_off;
   SIFSR_TRY(launch_dgrad_border_fix(dy_stored ? dy : a.dy_border, 16, wdg_f32, 16, gin, 16, 16, gin, 16, c.B, lh, lw, c.s, c.bf16,
                                     fuse ? a.bn_y : nullptr, fuse ? a.bn_scale : nullptr, fuse ? a.bn_shift : nullptr,
-                                    fuse ? c.f(c.lay.bpart) : nullptr));
+                                    fuse ? c.f(c.lay.bpart) : nullptr, a.store_dz));
   WgradReduceJob& j = c.xjobs[(*c.nxjobs)++];
   j.slab_off = c.lay.slab_l[l]; j.nblk = grid; j.cin = 16; j.cout = 16; j.nbi_chunk = 1; j.w_off = L.w_off;
   if (c.side != nullptr && hipEventRecord(c.side->ev[l], c.s) != hipSuccess) return SIFSR_ERR_ARG;   // slabs of l complete
@@ -621,6 +626,23 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   SideLaneGuard lane_guard(c.side, s);
   c.forked = &lane_guard.forked;
 
+  // SIFSR_HEAD_LINEAR=1 (A/B; off by default): the first layer's weight gradient in its linear form (edge_conv.hip: dW = sd * D +
+  // k1 * (W G) + k0 * X): the Gram matrix G and the sums X of the input patches depend on the network input alone -- second stream,
+  // now; D needs dz of inbloc.bloc.0, which the fused kernel of inbloc.bloc.3 stores in place of g.  One 16-channel tensor less to
+  // read (the D pass: 75 us against 136 us for the fused head kernel, stand-alone), but the Gram kernel costs 93 us of vector
+  // issue beside the chain's first kernels: 10,390 against 10,420 patches/s on the step (same device, interleaved) -- not adopted.
+  static const int head_linear_env = getenv("SIFSR_HEAD_LINEAR") ? atoi(getenv("SIFSR_HEAD_LINEAR")) : 0;
+  const bool head_linear = head_linear_env != 0 && bwd16_usable(c, L_IN3, src_act(c, L_IN0));
+  if (head_linear) {
+    hipStream_t gs = s;
+    if (c.side != nullptr) {
+      if (hipEventRecord(c.side->ev[L_IN0], s) != hipSuccess || hipStreamWaitEvent(c.side->s, c.side->ev[L_IN0], 0) != hipSuccess) return SIFSR_ERR_ARG;
+      lane_guard.forked = true;
+      gs = c.side->s;
+    }
+    SIFSR_TRY(launch_conv_in_gram(x, c.f(w.gram), B, H, W, gs));
+    if (c.side != nullptr && hipEventRecord(c.side->aux, gs) != hipSuccess) return SIFSR_ERR_ARG;
+  }
   static const int tail_apply_forced = getenv("SIFSR_TAIL_APPLY") ? atoi(getenv("SIFSR_TAIL_APPLY")) : 0;   // 1: keep the separate second pass (A/B)
   bool tail_in_bwd16 = false;
   // outlay backward fused with the BatchNorm+ReLU backward of ub3.convbloc.bloc.3 (fused_edges.hip): the outlay
@@ -713,7 +735,8 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   SIFSR_TRY(bn_unit_bwd(c, L_IN3, c.f(w.g[L_IN3]), grads, c.f(w.gP[0])));
   int rows_in0 = 0;
   bool fused_in3 = false;
-  SIFSR_TRY(conv_unit_bwd16(c, L_IN3, src_act(c, L_IN0), c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), nullptr, L_IN0, &rows_in0, 1, &fused_in3));
+  SIFSR_TRY(conv_unit_bwd16(c, L_IN3, src_act(c, L_IN0), c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), nullptr, L_IN0, &rows_in0, 1, &fused_in3, head_linear));
+  if (head_linear && !fused_in3) return SIFSR_ERR_ARG;
   if (!fused_in3) SIFSR_TRY(conv_unit_wgrad(c, L_IN3, src_act(c, L_IN0), src_none(), c.f(w.g[L_IN3]), grads));
   // that was the last MFMA layer: all 16 layers' weight-gradient slabs -> OIHW gradients, one launch.  With the second
   // stream it follows the last weight gradient there (it writes only the conv-weight regions of `grads`, which nothing
@@ -745,10 +768,18 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
                                        reinterpret_cast<double*>(c.f(w.coef)), s));
     }
     int nblk = B * ((H + 15) / 16) * ((W + 15) / 16);
-    if (nblk > 1024) nblk = 1024;
-    SIFSR_TRY(launch_conv_in_wgrad_fused(x, c.f(w.g[L_IN0]), y, c.scale(L_IN0), c.shift(L_IN0),
-                                         reinterpret_cast<const double*>(c.f(w.coef)), c.f(w.slabs), nblk,
-                                         grads + L.w_off, B, H, W, s));
+    if (head_linear) {      // g[L_IN0] holds dz
+      if (nblk > 768) nblk = 768;
+      SIFSR_TRY(launch_conv_in_dz_wgrad(x, c.f(w.g[L_IN0]), c.f(w.slabs), nblk, B, H, W, s));
+      if (c.side != nullptr && hipStreamWaitEvent(s, c.side->aux, 0) != hipSuccess) return SIFSR_ERR_ARG;
+      SIFSR_TRY(launch_conv_in_dw_combine(c.f(w.slabs), nblk, conv_in_gram_result(c.f(w.gram)), params + L.w_off,
+                                          reinterpret_cast<const double*>(c.f(w.coef)), grads + L.w_off, s));
+    } else {
+      if (nblk > 1024) nblk = 1024;
+      SIFSR_TRY(launch_conv_in_wgrad_fused(x, c.f(w.g[L_IN0]), y, c.scale(L_IN0), c.shift(L_IN0),
+                                           reinterpret_cast<const double*>(c.f(w.coef)), c.f(w.slabs), nblk,
+                                           grads + L.w_off, B, H, W, s));
+    }
   }
   if (c.side != nullptr) {   // hand the second stream's work back to the caller's stream
     SIFSR_TRY(lane_guard.join());

@@ -501,7 +501,7 @@ def test_fused_tail_backward(L, shape):
         assert rel_err(dwb.cpu()[144:], gbias) < TOL
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 16, 16)])
+@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 16, 16), (2, 24, 40), (8, 128, 128)])
 def test_fused_head_backward(L, shape):
     """sifsr_conv_in_bn_relu_bwd == autograd of relu(bn(conv_in(x))) w.r.t. (w_in, gamma, beta)"""
     B, H, W = shape
@@ -525,6 +525,14 @@ def test_fused_head_backward(L, shape):
     torch.cuda.synchronize()
     assert rel_err(dw.cpu(), gw) < TOL
     assert rel_err(dgam.cpu(), gg) < TOL and rel_err(dbet.cpu(), gb) < TOL
+    # the linear form (round 3): the same dW from dz = g*[z > 0], the coefficients just returned, and the network input alone
+    dz = dev(nhwc(g)) * ((dev(nhwc(y.detach())) * scale + shift) > 0)
+    for nb in (3, B * ((H + 15) // 16) * ((W + 15) // 16)):
+        sc2 = torch.empty(L.call("sifsr_conv_in_bwd_linear_scratch_floats", nb), device="cuda")
+        dw2 = torch.full((16, 2, 3, 3), float("nan"), device="cuda")
+        L.call("sifsr_conv_in_bwd_linear", dev(x), dz.contiguous(), dev(w.detach()), coef, sc2, nb, dw2, B, H, W, S())
+        torch.cuda.synchronize()
+        assert rel_err(dw2.cpu(), gw) < TOL, (nb, rel_err(dw2.cpu(), gw))
 
 
 # ---- BatchNorm+ReLU backward fused into the input- and weight-gradient convolutions (round 2) --------------------

@@ -1,6 +1,6 @@
 """The library's A/B switches select other kernels for the same maths: SIFSR_WGRAD_WINO=0 (tap-domain weight gradients),
 SIFSR_NO_WINO8=1 (producer / consumer Winograd kernels for 32 / 64 output channels), SIFSR_NO_WINO=1 (tap-domain forward and
-input gradients).  The switches are read once per process, so each runs in its own process: the same seeded SR2 step must give
+input gradients), SIFSR_NO_BWD16=1 / SIFSR_TAIL_APPLY=1 / SIFSR_HEAD_LINEAR=1 (round 3: the backward's fused kernels and their alternatives).  The switches are read once per process, so each runs in its own process: the same seeded SR2 step must give
 the same loss and gradients as the default configuration to fp32 rounding (the kernels differ in summation order only), and the
 default itself is pinned to the oracle by tests/test_model_gpu.py."""
 import os
@@ -45,14 +45,18 @@ def test_kernel_switches_agree_with_the_default_configuration(tmp_path):
     ref = _run(tmp_path, "default", {})
     gmax = float(ref["grad"].abs().max())
     for tag, env in [("tap_wgrad", {"SIFSR_WGRAD_WINO": "0"}), ("no_wino8", {"SIFSR_NO_WINO8": "1"}),
-                     ("no_wino", {"SIFSR_NO_WINO": "1"}), ("single_stream", {"SIFSR_WGRAD_STREAM": "0"})]:
+                     ("no_wino", {"SIFSR_NO_WINO": "1"}), ("single_stream", {"SIFSR_WGRAD_STREAM": "0"}),
+                     # round 3: separate input / weight gradient kernels for the 16 -> 16 layers; the tail's dL/dy stored by a
+                     # second pass instead of recomputed in the fused kernel; the first layer's weight gradient in its linear form
+                     ("no_bwd16", {"SIFSR_NO_BWD16": "1"}), ("tail_apply", {"SIFSR_TAIL_APPLY": "1"}),
+                     ("head_linear", {"SIFSR_HEAD_LINEAR": "1"})]:
         got = _run(tmp_path, tag, env)
         assert abs(got["loss"] - ref["loss"]) <= 1e-5 * abs(ref["loss"]), tag
         assert float((got["sr"] - ref["sr"]).abs().max()) <= 1e-4 * float(ref["sr"].abs().max()), tag
         # gradients: a handful of ReLU decisions may flip when the forward kernels differ, so the bar is
         # on the bulk: relative L2 over all 282,705 parameters
         rel = float((got["grad"] - ref["grad"]).norm() / ref["grad"].norm())
-        assert rel <= (1e-5 if tag in ("tap_wgrad", "single_stream") else 2e-3), (tag, rel)
+        assert rel <= (1e-5 if tag in ("tap_wgrad", "single_stream", "no_bwd16", "tail_apply", "head_linear") else 2e-3), (tag, rel)
         if tag == "single_stream":
             assert torch.equal(got["grad"], ref["grad"]), "the second stream must not change a bit"
         assert float((got["grad"] - ref["grad"]).abs().max()) <= 0.05 * gmax, tag
