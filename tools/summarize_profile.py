@@ -32,7 +32,10 @@ def pmc(kind):
 
 
 fetch, write = pmc("fetch"), pmc("write")
-lines = [f"# rocprofv3 summary `{tag}` — bench.py --steps 5 --warmup 2 (N=1, batch 64, SR2, fp32)", "",
+mode = "--dtype bf16: bf16 stored activations, bf16 MFMA operands" if "bf16" in tag else "fp32"
+if "single" in tag:
+    mode += "; SIFSR_WGRAD_STREAM=0, everything on one stream"
+lines = [f"# rocprofv3 summary `{tag}` — bench.py --steps 5 --warmup 2 (N=1, batch 64, SR2, {mode})", "",
          f"Total kernel time {tot/1e6:.1f} ms over {steps} steps = **{tot/1e6/steps:.2f} ms/step**.", "",
          "| kernel | calls | avg µs | ms/step | % | HBM read MB/launch (2×FETCH_SIZE) | HBM write MB/launch |", "|---|---|---|---|---|---|---|"]
 for r in rows[:30]:
