@@ -10,7 +10,7 @@ import csv, glob, os, shutil, sys, collections
 src, tag = sys.argv[1], sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(f"{src}/stats/*/*kernel_stats.csv")[0]
+stats = max(glob.glob(f"{src}/stats/*/*kernel_stats.csv"), key=os.path.getmtime)   # (gpurun merges runs into the same directory: newest)
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -25,7 +25,7 @@ def pmc(kind):
     if not f:
         return {}
     acc = collections.defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(max(f, key=os.path.getmtime))):
         k = short(r["Kernel_Name"])
         acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
     return {k: v[0] / v[1] for k, v in acc.items()}

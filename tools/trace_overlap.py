@@ -4,7 +4,7 @@ import csv, glob, os, sys
 
 def main():
     d = sys.argv[1]
-    f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[-1]
+    f = max(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)   # newest run in the directory
     rows = []
     with open(f) as fh:
         for r in csv.DictReader(fh):
