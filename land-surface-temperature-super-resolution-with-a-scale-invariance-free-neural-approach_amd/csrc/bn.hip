@@ -10,27 +10,36 @@
 
 namespace {
 
+// (s1, s2) summed over the workgroup in float64, fixed order: butterfly inside each wave, then the waves in order -- ONE barrier
+// (the 8-level LDS tree that stood here cost 8 barriers in ~30 launches per step that do nothing else; they sit on the serial chain)
+template <int NT>
+static __device__ __forceinline__ void block_sum2(double& s1, double& s2, double (*wsum)[2]) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { wsum[wave][0] = s1; wsum[wave][1] = s2; }
+  __syncthreads();
+  s1 = 0.0; s2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) { s1 += wsum[w][0]; s2 += wsum[w][1]; }
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
                                                           double count, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* run_mean,
                                                           float* run_var, float momentum, float eps, float* mean,
                                                           float* invstd, float* scale, float* shift) {
-  __shared__ double r1[256], r2[256];
+  __shared__ double wsum[4][2];
   const int c = blockIdx.x, tid = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int k = tid; k < nblk; k += 256) {
-    s1 += (double)partials[((size_t)k * C + c) * 2 + 0];
-    s2 += (double)partials[((size_t)k * C + c) * 2 + 1];
+    const float2 v = *reinterpret_cast<const float2*>(partials + ((size_t)k * C + c) * 2);
+    s1 += (double)v.x; s2 += (double)v.y;
   }
-  r1[tid] = s1; r2[tid] = s2;
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (tid < st) { r1[tid] += r1[tid + st]; r2[tid] += r2[tid + st]; }
-    __syncthreads();
-  }
+  block_sum2<256>(s1, s2, wsum);
   if (tid == 0) {
-    const double m = r1[0] / count;
-    double var = r2[0] / count - m * m;
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
     const float istd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * istd;
@@ -149,21 +158,16 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               float* dbeta, double* coef, const float* __restrict__ shift,
                                                               const float* __restrict__ beta, float* coef_f) {
   SIFSR_CHAIN_PRIO();
-  __shared__ double r1[256], r2[256];
+  __shared__ double wsum[4][2];
   const int c = blockIdx.x, tid = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int k = tid; k < nblk; k += 256) {
-    s1 += (double)partials[((size_t)k * C + c) * 2 + 0];
-    s2 += (double)partials[((size_t)k * C + c) * 2 + 1];
+    const float2 v = *reinterpret_cast<const float2*>(partials + ((size_t)k * C + c) * 2);
+    s1 += (double)v.x; s2 += (double)v.y;
   }
-  r1[tid] = s1; r2[tid] = s2;
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (tid < st) { r1[tid] += r1[tid + st]; r2[tid] += r2[tid + st]; }
-    __syncthreads();
-  }
+  block_sum2<256>(s1, s2, wsum);
   if (tid == 0) {
-    const double db = r1[0], dg = r2[0];
+    const double db = s1, dg = s2;
     dbeta[c] = (float)db;
     dgamma[c] = (float)dg;
     // dy = scale*dz + k1*y + k0, kept in float64: the three terms cancel to << |scale*dz| when the
@@ -187,20 +191,15 @@ __global__ __launch_bounds__(NT) void bn_bwd_finalize2_kernel(const float* __res
                                                                float* dbeta, double* coef, const float* __restrict__ shift,
                                                                const float* __restrict__ beta, float* coef_f) {
   SIFSR_CHAIN_PRIO();
-  __shared__ double r1[NT], r2[NT];
+  __shared__ double wsum[NT / 64][2];
   const int c = blockIdx.x, tid = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = tid; k < na; k += NT) { s1 += (double)pa[((size_t)k * C + c) * 2]; s2 += (double)pa[((size_t)k * C + c) * 2 + 1]; }
-  for (int k = tid; k < nb; k += NT) { s1 += (double)pb[((size_t)k * C + c) * 2]; s2 += (double)pb[((size_t)k * C + c) * 2 + 1]; }
-  r1[tid] = s1; r2[tid] = s2;
-  __syncthreads();
-  for (int st = NT / 2; st > 0; st >>= 1) {
-    if (tid < st) { r1[tid] += r1[tid + st]; r2[tid] += r2[tid + st]; }
-    __syncthreads();
-  }
+  for (int k = tid; k < na; k += NT) { const float2 v = *reinterpret_cast<const float2*>(pa + ((size_t)k * C + c) * 2); s1 += (double)v.x; s2 += (double)v.y; }
+  for (int k = tid; k < nb; k += NT) { const float2 v = *reinterpret_cast<const float2*>(pb + ((size_t)k * C + c) * 2); s1 += (double)v.x; s2 += (double)v.y; }
+  block_sum2<NT>(s1, s2, wsum);
   if (tid == 0) {
-    const double db = r1[0];
-    const double dg = (double)invstd[c] * (r2[0] - (double)mean[c] * db);
+    const double db = s1;
+    const double dg = (double)invstd[c] * (s2 - (double)mean[c] * db);
     dbeta[c] = (float)db;
     dgamma[c] = (float)dg;
     const double k1 = -(double)scale[c] * (double)invstd[c] * dg / count;

@@ -131,4 +131,6 @@ int launch_dgrad_border_fix(const float* dy, int Cout, const float* wdg_layer, i
 int dgrad_border_waves(int B, int H, int W, int Cin);   // rows of bn_partials ([wave][16][2]) the border kernel writes
 
 // wwf / wwd (optional): Winograd-domain packs of all layers, 16/9 of the size and offsets of wfwd
-int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStream_t s, float* wwf = nullptr, float* wwd = nullptr);
+// nbt (optional, with the Winograd packs): nbt_n int64 counters incremented by the same launch (BatchNorm num_batches_tracked)
+int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStream_t s, float* wwf = nullptr, float* wwd = nullptr,
+                        long long* nbt = nullptr, int nbt_n = 0);

@@ -754,13 +754,13 @@ __global__ __launch_bounds__(512, (WINO ? (NB == 1 && !ZERO_PAD ? 4 : 2) : (NB <
 // ---------------------------------------------------------------------------------------------
 struct PackTable { int w_off[16], cin[16], cout[16], p_off[16]; };
 
-__global__ void pack_weights_kernel(const float* __restrict__ params, float* __restrict__ wfwd,
-                                    float* __restrict__ wdg, const PackTable tb) {
+static __device__ __forceinline__ void pack_weights_body(const float* __restrict__ params, float* __restrict__ wfwd,
+                                                         float* __restrict__ wdg, const PackTable& tb, int bx, int gdx) {
   const int l = blockIdx.y;
   const int cin = tb.cin[l], cout = tb.cout[l];
   const int n = 9 * cin * cout;
   const float* W = params + tb.w_off[l];
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+  for (int e = bx * blockDim.x + threadIdx.x; e < n; e += gdx * blockDim.x) {
     const int j = e & 3, lane = (e >> 2) & 63;
     const int rest = e >> 8;
     const int tap = rest % 9, r2 = rest / 9;
@@ -792,15 +792,20 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
 // Winograd-domain weights U = G g G^T (4x4 per (cout, cin) pair; G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]) in
 // fragment order, for the forward (g = W[co][ci]) and for the input gradient (g = W[co][ci] transposed and flipped):
 //   ww[nb][q][xi][lane][j], xi = 4a + b, same (lane, j) -> (row, k) map as the tap packs above; 16*cin*cout floats each.
-__global__ void pack_wino_kernel(const float* __restrict__ params, float* __restrict__ wwf, float* __restrict__ wwd,
-                                 const PackTable tb) {
+__global__ void pack_weights_kernel(const float* __restrict__ params, float* __restrict__ wfwd,
+                                    float* __restrict__ wdg, const PackTable tb) {
+  pack_weights_body(params, wfwd, wdg, tb, blockIdx.x, gridDim.x);
+}
+
+static __device__ __forceinline__ void pack_wino_body(const float* __restrict__ params, float* __restrict__ wwf,
+                                                      float* __restrict__ wwd, const PackTable& tb, int bx, int gdx) {
   const int l = blockIdx.y;
   const int cin = tb.cin[l], cout = tb.cout[l];
   const int n = 16 * cin * cout;
   const float* W = params + tb.w_off[l];
   const size_t off = (size_t)tb.p_off[l] / 9 * 16;
   const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+  for (int e = bx * blockDim.x + threadIdx.x; e < n; e += gdx * blockDim.x) {
     const int j = e & 3, lane = (e >> 2) & 63;
     const int rest = e >> 8;
     const int xi = rest & 15, r2 = rest >> 4;
@@ -823,6 +828,18 @@ __global__ void pack_wino_kernel(const float* __restrict__ params, float* __rest
       (k == 0 ? wwf : wwd)[off + e] = u;
     }
   }
+}
+__global__ void pack_wino_kernel(const float* __restrict__ params, float* __restrict__ wwf, float* __restrict__ wwd,
+                                 const PackTable tb) {
+  pack_wino_body(params, wwf, wwd, tb, blockIdx.x, gridDim.x);
+}
+// all four packs of all layers (+ the BatchNorm num_batches_tracked counters of a training-mode forward) in ONE launch: the three
+// launches this replaces were 20 us at the head of every forward for < 2 us of work.  blockIdx.x < gx: tap packs; the rest: Winograd.
+__global__ void pack_all_kernel(const float* __restrict__ params, float* __restrict__ wfwd, float* __restrict__ wdg,
+                                float* __restrict__ wwf, float* __restrict__ wwd, const PackTable tb, int gx, long long* nbt, int nbt_n) {
+  if ((int)blockIdx.x < gx) pack_weights_body(params, wfwd, wdg, tb, blockIdx.x, gx);
+  else pack_wino_body(params, wwf, wwd, tb, (int)blockIdx.x - gx, (int)gridDim.x - gx);
+  if (nbt != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < nbt_n) nbt[threadIdx.x] += 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1108,7 +1125,7 @@ int launch_conv3x3_mfma(const ConvArgs& a, int cout, int zero_pad, hipStream_t s
   return SIFSR_OK;
 }
 
-int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStream_t s, float* wwf, float* wwd) {
+int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStream_t s, float* wwf, float* wwd, long long* nbt, int nbt_n) {
   const NetTable& nt = sifsr_net();
   PackTable tb;
   int maxn = 0;
@@ -1121,12 +1138,14 @@ int launch_pack_weights(const float* params, float* wfwd, float* wdgrad, hipStre
     maxn = n > maxn ? n : maxn;
   }
   const dim3 grid((maxn + 255) / 256 > 64 ? 64 : (maxn + 255) / 256, 16);
-  hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, s, params, wfwd, wdgrad, tb);
-  SIFSR_LAUNCH_CHECK();
+  if (nbt != nullptr && (nbt_n < 1 || nbt_n > 256)) return SIFSR_ERR_ARG;
   if (wwf != nullptr && wwd != nullptr) {
-    hipLaunchKernelGGL(pack_wino_kernel, dim3(grid.x * 2, 16), dim3(256), 0, s, params, wwf, wwd, tb);
-    SIFSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pack_all_kernel, dim3(grid.x * 3, 16), dim3(256), 0, s, params, wfwd, wdgrad, wwf, wwd, tb, (int)grid.x, nbt, nbt_n);
+  } else {
+    if (nbt != nullptr) return SIFSR_ERR_ARG;
+    hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, s, params, wfwd, wdgrad, tb);
   }
+  SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }
 

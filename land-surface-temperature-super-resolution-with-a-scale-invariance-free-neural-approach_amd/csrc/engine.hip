@@ -544,10 +544,8 @@ int sifsr_engine_forward(const float* x, float* sr, const float* params, float* 
   const NetTable& nt = c.nt;
   const WsLayout& w = c.lay;
 
-  SIFSR_TRY(launch_pack_weights(params, c.f(w.wfwd), c.f(w.wdg), s, c.f(w.wwf), c.f(w.wwd)));
-  if (training) {
-    if (nbt) SIFSR_TRY(launch_nbt_increment(nbt, SIFSR_NUM_BN_LAYERS, s));
-  } else {
+  SIFSR_TRY(launch_pack_weights(params, c.f(w.wfwd), c.f(w.wdg), s, c.f(w.wwf), c.f(w.wwd), training ? nbt : nullptr, SIFSR_NUM_BN_LAYERS));
+  if (!training) {
     SIFSR_TRY(launch_bn_eval_coeffs(params, running, eps, c.f(w.scale), c.f(w.shift), s));
   }
 
