@@ -190,6 +190,27 @@ class _SifLoss(torch.autograd.Function):
         return dsr * g_loss, None, None, None, None, None, None, None
 
 
+def sif_loss_with_grad(kind, sr, lst, ndvi, mean, std, alpha, gamma):
+    """The same fused loss block WITHOUT an autograd node: returns (ds_loss, percep_loss, loss, d loss / d sr).  A training step
+    that ends in ``loss.backward()`` seeds the graph with ones_like(loss) and multiplies d loss / d sr by it -- a fill and a
+    16 MB elementwise launch on the serial chain; ``sr.backward(dsr)`` with this gradient is the same step without them
+    (train.train_step).  ``sr`` may carry a graph; it is only read."""
+    srd, lst, ndvi = sr.detach().contiguous(), lst.contiguous(), ndvi.contiguous()
+    for t, n in ((srd, "sr"), (lst, "lst"), (ndvi, "ndvi")):
+        _lib.require_gpu(t, n)
+    B, C, H, W = srd.shape
+    if C != 1 or tuple(ndvi.shape) != (B, 1, H, W) or tuple(lst.shape) != (B, 1, H // 4, W // 4):
+        raise _lib.SifsrError("sif_loss expects sr (B,1,H,W), lst (B,1,H/4,W/4), ndvi (B,1,H,W)")
+    k = {"sr2": 2, "sr1": 1}[kind]
+    ws_bytes = _lib.call("sifsr_sif_loss_workspace_bytes", k, B, H, W)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=srd.device)
+    losses = torch.empty(3, dtype=torch.float32, device=srd.device)
+    dsr = torch.empty_like(srd)
+    _lib.call("sifsr_sif_loss", k, srd, lst, ndvi, B, H, W, float(mean), float(std), float(alpha), float(gamma),
+              _taps_c(0.1, 4, None), _taps_c(0.25, 4, None), ws, ws_bytes, losses, dsr, _lib.stream_ptr(srd.device))
+    return losses[0], losses[1], losses[2], dsr
+
+
 def sif_loss(kind, sr, lst, ndvi, mean, std, alpha, gamma):
     """Fused loss block of the training step.  kind='sr2': train_model_B_gradFTM.py:99-117;
     kind='sr1': train_model_B_predef_filters.py:111-133.  Returns (ds_loss, percep_loss, loss) as

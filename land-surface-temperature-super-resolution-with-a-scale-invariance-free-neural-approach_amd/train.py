@@ -13,7 +13,7 @@ import torch
 
 from . import distributed as dp
 from . import metrics as _metrics
-from .sif_ops import huber_loss, sif_loss
+from .sif_ops import huber_loss, sif_loss, sif_loss_with_grad
 
 
 def train_step(model, optimizer, lst, lst_up, ndvi, stats, alpha, gamma, kind="sr2", sync_grads=True, return_sr=False):
@@ -27,8 +27,9 @@ def train_step(model, optimizer, lst, lst_up, ndvi, stats, alpha, gamma, kind="s
     optimizer.zero_grad(set_to_none=True)
     lst_ndvi = torch.cat((lst_up, ndvi), dim=1)
     sr = model(lst_ndvi)
-    ds, pl, loss = sif_loss(kind, sr, lst, ndvi, stats["mean_lst"], stats["std_lst"], alpha, gamma)
-    loss.backward()
+    # loss.backward() == sr.backward(d loss / d sr): the fused loss op returns that gradient directly (sif_ops.sif_loss_with_grad)
+    ds, pl, loss, dsr = sif_loss_with_grad(kind, sr, lst, ndvi, stats["mean_lst"], stats["std_lst"], alpha, gamma)
+    sr.backward(dsr)
     if sync_grads:
         dp.allreduce_gradients(model, optimizer)
     optimizer.step()

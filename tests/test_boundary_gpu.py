@@ -242,6 +242,34 @@ def test_dropin_import_surface_runs_the_sr2_step(sifsr, golden, dropin):
         us.read_LST("x.hdf", "day")
 
 
+@pytest.mark.parametrize("kind", ["sr2", "sr1"])
+def test_train_step_gradient_shortcut_equals_loss_backward(sifsr, kind):
+    """train_step seeds the backward with d loss / d sr from the fused loss op (sr.backward(dsr)) instead of loss.backward():
+    same losses, bit-identical gradients."""
+    import sifsr as S
+    torch.manual_seed(3)
+    dev = torch.device("cuda", 0)
+    stats = dict(S.dataset.DEFAULT_STATS)
+    lst, lst_up, ndvi = S.dataset.synthetic_device_batch(2, dev, seed=5, hr=64)
+    sd = O.synthetic_state(17)
+    grads = []
+    for shortcut in (False, True):
+        m = S.ModelB_2(2, [16, 32, 64, 128], "replicate", "ReLU", 1, 1).to(dev)
+        m.load_state_dict(sd)
+        m.train()
+        sr = m(torch.cat((lst_up, ndvi), dim=1))
+        if shortcut:
+            ds, pl, loss, dsr = S.sif_ops.sif_loss_with_grad(kind, sr, lst, ndvi, stats["mean_lst"], stats["std_lst"], 0.5, -0.25)
+            sr.backward(dsr)
+        else:
+            ds, pl, loss = S.sif_loss(kind, sr, lst, ndvi, stats["mean_lst"], stats["std_lst"], 0.5, -0.25)
+            loss.backward()
+        torch.cuda.synchronize()
+        grads.append((float(ds), float(pl), float(loss), m.flat_grad().detach().clone()))
+    assert grads[0][:3] == grads[1][:3]
+    assert torch.equal(grads[0][3], grads[1][3])
+
+
 def test_train_mode_forward_without_grad(sifsr):
     """``model.train()`` under ``torch.no_grad()`` (BatchNorm recalibration / frozen-model passes): nn.Module accepts it,
     uses batch statistics and updates the running statistics.  Round 1 sized the workspace for an eval forward and the
