@@ -156,10 +156,28 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* dgamma,
                                                               float* dbeta, double* coef, const float* __restrict__ shift,
-                                                              const float* __restrict__ beta, float* coef_f) {
+                                                              const float* __restrict__ beta, float* coef_f,
+                                                              const float* __restrict__ xs_partials, int xs_n, float* __restrict__ xs_out) {
   SIFSR_CHAIN_PRIO();
   __shared__ double wsum[4][2];
   const int c = blockIdx.x, tid = threadIdx.x;
+  if (c >= C) {
+    // rider (the tail of the backward): xs_out[e] = sum over the nblk rows of xs_partials[row][xs_n] -- the outlay weight / bias
+    // gradient partials of the same pass; four outputs per extra workgroup, float64, fixed order (as sum_partials_kernel)
+    __shared__ double part[64][4];
+    const int el = tid & 3, grp = tid >> 2, e = (c - C) * 4 + el;
+    double s = 0.0;
+    if (e < xs_n)
+      for (int k = grp; k < nblk; k += 64) s += (double)xs_partials[(size_t)k * xs_n + e];
+    part[grp][el] = s;
+    __syncthreads();
+    if (grp == 0 && e < xs_n) {
+      double t = 0.0;
+      for (int g = 0; g < 64; ++g) t += part[g][el];
+      xs_out[e] = (float)t;
+    }
+    return;
+  }
   double s1 = 0.0, s2 = 0.0;
   for (int k = tid; k < nblk; k += 256) {
     const float2 v = *reinterpret_cast<const float2*>(partials + ((size_t)k * C + c) * 2);
@@ -292,10 +310,12 @@ int launch_bn_bwd_reduce(const float* g, const float* y, const float* scale, con
 
 int launch_bn_bwd_finalize(const float* partials, int nblk, int C, double count, const float* scale, const float* mean,
                            const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s, const float* shift,
-                           const float* beta, float* coef_f) {
+                           const float* beta, float* coef_f, const float* xs_partials, int xs_n, float* xs_out) {
   if (coef_f != nullptr && (!shift || !beta)) return SIFSR_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, partials, nblk, C, count, scale, mean, invstd,
-                     dgamma, dbeta, coef, shift, beta, coef_f);
+  if (xs_partials != nullptr && (xs_n < 1 || !xs_out)) return SIFSR_ERR_ARG;
+  const int extra = xs_partials != nullptr ? (xs_n + 3) / 4 : 0;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C + extra), dim3(256), 0, s, partials, nblk, C, count, scale, mean, invstd,
+                     dgamma, dbeta, coef, shift, beta, coef_f, xs_partials, xs_n, xs_out);
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
 }

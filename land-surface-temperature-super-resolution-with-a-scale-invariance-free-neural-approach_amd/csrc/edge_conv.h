@@ -47,7 +47,9 @@ int launch_bn_bwd_reduce(const float* g, const float* y, const float* scale, con
 // coef_f (optional, needs shift and beta): 4 x C fp32 [sc | sh | k1 | k0] of bn_bwd4 (dy = sc*dz + k1*z + k0 on z = y*sc + sh)
 int launch_bn_bwd_finalize(const float* partials, int nblk, int C, double count, const float* scale, const float* mean,
                            const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s,
-                           const float* shift = nullptr, const float* beta = nullptr, float* coef_f = nullptr);
+                           const float* shift = nullptr, const float* beta = nullptr, float* coef_f = nullptr,
+                           const float* xs_partials = nullptr, int xs_n = 0, float* xs_out = nullptr);   // xs_*: a rider, xs_out[e] =
+                           // the column sums of xs_partials[nblk][xs_n] (same row count) -- one launch less on the chain
 int launch_bn_bwd_finalize2(const float* pa, int na, const float* pb, int nb, int C, double count, const float* scale,
                             const float* mean, const float* invstd, float* dgamma, float* dbeta, double* coef, hipStream_t s,
                             const float* shift = nullptr, const float* beta = nullptr, float* coef_f = nullptr);

@@ -653,13 +653,12 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     SIFSR_TRY(launch_tail_bwd_reduce(y, c.scale(L_U3B), c.shift(L_U3B), c.f(w.mean) + L.ch_off, c.f(w.invstd) + L.ch_off, dsr,
                                      params + nt.out_w_off, c.f(w.slabs), c.f(w.partials), nblk, B, H, W, s));
     if (grads + nt.out_b_off != grads + nt.out_w_off + 144) return SIFSR_ERR_ARG;
-    SIFSR_TRY(launch_sum_partials(c.f(w.slabs), nblk, 145, grads + nt.out_w_off, s));
     // with the fused 16 -> 16 backward kernel the second pass is part of that kernel's staging (conv_bwd16.hip, mode 2)
     tail_in_bwd16 = !tail_apply_forced && bwd16_usable(c, L_U3B, src_act(c, L_U3A));
     SIFSR_TRY(launch_bn_bwd_finalize(c.f(w.partials), nblk, 16, (double)w.npix[0], c.scale(L_U3B), c.f(w.mean) + L.ch_off,
                                      c.f(w.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
                                      reinterpret_cast<double*>(c.f(w.coef)), s, c.shift(L_U3B), params + L.beta_off,
-                                     c.f(w.coef_f) + 4 * (size_t)L.ch_off));
+                                     c.f(w.coef_f) + 4 * (size_t)L.ch_off, c.f(w.slabs), 145, grads + nt.out_w_off));   // (+ outlay dW / db)
     if (!tail_in_bwd16)
       SIFSR_TRY(launch_tail_bwd_apply(y, c.scale(L_U3B), c.shift(L_U3B), reinterpret_cast<const double*>(c.f(w.coef)), dsr,
                                       params + nt.out_w_off, c.f(w.g[L_U3B]), B, H, W, s));

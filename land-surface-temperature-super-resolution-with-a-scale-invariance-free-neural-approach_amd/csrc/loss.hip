@@ -407,10 +407,15 @@ __global__ __launch_bounds__(256) void sif_loss_fwd_kernel(const float* __restri
   if (tid == 0) { partials[blk * 2] = h1; partials[blk * 2 + 1] = h2; }
 }
 
+// fin_*: the loss values (the job of loss_finalize_kernel) are reduced by workgroup (0,0,0) of THIS launch after its tile -- the
+// gradient does not depend on them (w1, w2 are constants), and a separate 7 us launch between the two passes sat on the serial chain
 template <int KIND>
 __global__ __launch_bounds__(256) void sif_loss_bwd_kernel(const float* __restrict__ r1, const float* __restrict__ r2,
-                                                           Taps k1, Taps k2, float* __restrict__ dsr, int H, int W) {
+                                                           Taps k1, Taps k2, float* __restrict__ dsr, int H, int W,
+                                                           const float* __restrict__ fin_partials, int fin_nblk, float fin_sc0,
+                                                           float fin_sc1, float fin_alpha, float* __restrict__ fin_out) {
   __shared__ float L[TP * LS], M[TP * LS];
+  __shared__ double fin_w[4][2];
   const int tid = threadIdx.x, x0 = blockIdx.x * T, y0 = blockIdx.y * T;
   const int tx = tid & 31, ty = tid >> 5;
   const size_t img = (size_t)blockIdx.z * H * W;
@@ -454,6 +459,20 @@ __global__ __launch_bounds__(256) void sif_loss_bwd_kernel(const float* __restri
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (y0 + ty + 8 * r < H && x0 + tx < W) dsr[img + (size_t)(y0 + ty + 8 * r) * W + x0 + tx] = acc[r];
+  if (fin_out != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {   // (workgroup-uniform)
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = tid; k < fin_nblk; k += 256) { s0 += (double)fin_partials[2 * (size_t)k]; s1 += (double)fin_partials[2 * (size_t)k + 1]; }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) { s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); }
+    if ((tid & 63) == 0) { fin_w[tid >> 6][0] = s0; fin_w[tid >> 6][1] = s1; }
+    __syncthreads();
+    if (tid == 0) {
+      const float l0 = (float)((fin_w[0][0] + fin_w[1][0] + fin_w[2][0] + fin_w[3][0]) * (double)fin_sc0);
+      const float l1 = (float)((fin_w[0][1] + fin_w[1][1] + fin_w[2][1] + fin_w[3][1]) * (double)fin_sc1);
+      fin_out[0] = l0; fin_out[1] = l1;
+      fin_out[2] = fin_alpha * l0 + (1.f - fin_alpha) * l1;   // loss = alpha*ds + (1-alpha)*percep
+    }
+  }
 }
 
 inline Taps make_taps(const float* t9) { Taps k; for (int i = 0; i < 9; ++i) k.w[i] = t9[i]; return k; }
@@ -539,10 +558,11 @@ int launch_sif_loss(int kind, const float* sr, const float* lst, const float* nd
   } else {
     hipLaunchKernelGGL((sif_loss_fwd_kernel<1>), grid, dim3(256), 0, s, sr, lst, ndvi, k1, k2, mean, std, gamma, w1, w2, r1, r2, partials, H, W);
   }
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, partials, nblk, 2, 2, (float)(1.0 / n1), (float)(1.0 / n2), alpha, losses3);
   if (dsr != nullptr) {
-    if (kind == 2) hipLaunchKernelGGL((sif_loss_bwd_kernel<2>), grid, dim3(256), 0, s, r1, r2, k1, k2, dsr, H, W);
-    else hipLaunchKernelGGL((sif_loss_bwd_kernel<1>), grid, dim3(256), 0, s, r1, r2, k1, k2, dsr, H, W);
+    if (kind == 2) hipLaunchKernelGGL((sif_loss_bwd_kernel<2>), grid, dim3(256), 0, s, r1, r2, k1, k2, dsr, H, W, partials, nblk, (float)(1.0 / n1), (float)(1.0 / n2), alpha, losses3);
+    else hipLaunchKernelGGL((sif_loss_bwd_kernel<1>), grid, dim3(256), 0, s, r1, r2, k1, k2, dsr, H, W, partials, nblk, (float)(1.0 / n1), (float)(1.0 / n2), alpha, losses3);
+  } else {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, partials, nblk, 2, 2, (float)(1.0 / n1), (float)(1.0 / n2), alpha, losses3);
   }
   SIFSR_LAUNCH_CHECK();
   return SIFSR_OK;
