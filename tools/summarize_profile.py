@@ -108,7 +108,7 @@ cats = collections.OrderedDict([
     ("thin convs (in/out)", lambda k: "conv_in" in k or "conv_out" in k or "sum_partials" in k),
     ("pool / upsample / residual", lambda k: "pool2" in k or "up2x" in k or "bnrelu_add" in k),
     ("SIF loss", lambda k: "sif_loss" in k or "loss_finalize" in k or "blur" in k or "huber" in k or "sobel" in k),
-    ("Adam + weight pack", lambda k: "adam" in k or "pack_weights" in k),
+    ("Adam + weight pack", lambda k: "adam" in k or "pack_weights" in k or "pack_wino" in k or "pack_all" in k),
 ])
 agg = collections.OrderedDict((c, 0.0) for c in cats); agg["other (torch cat/copies)"] = 0.0
 for r in rows:

@@ -10,8 +10,8 @@ def main():
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")))
     rows.sort()
-    # last step = from the last pack_weights kernel to the end
-    idx = [i for i, r in enumerate(rows) if "pack_weights" in r[2]]
+    # last step = from the last weight-pack kernel (the head of a forward) to the end
+    idx = [i for i, r in enumerate(rows) if "pack_all_kernel" in r[2] or "pack_weights_kernel" in r[2]]
     lo = idx[-1]
     step = rows[lo:]
     t0 = step[0][0]
