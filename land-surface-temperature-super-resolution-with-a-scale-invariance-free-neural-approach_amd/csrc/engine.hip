@@ -671,6 +671,7 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   // the upsample adjoint that completes g of a low-resolution layer also leaves that layer's BatchNorm-backward sums (one
   // row per workgroup): up_rows > 0 tells the next bn_unit_bwd of that layer to skip its reduce pass
   int up_rows = 0;
+  int last_fused = -1;   // the last layer whose slabs the fused 16 -> 16 kernel wrote on the caller's stream (its ev[] marks them complete)
   for (int k = 2; k >= 0; --k) {
     const int lv = 2 - k;
     const int la = dec_a[k], lb = dec_b[k], ls = dec_skip[k], ll = dec_low[k];
@@ -680,6 +681,7 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
     bool fused_b = false;
     SIFSR_TRY(conv_unit_bwd16(c, lb, src_act(c, la), k == 2 && tail_in_bwd16 ? dsr : c.f(w.g[lb]), c.f(w.g[la]), nullptr, la, &rows_a,
                               k == 2 ? (tail_in_bwd16 ? 2 : 0) : 1, &fused_b));
+    if (fused_b) last_fused = lb;
     if (!fused_b) {
       SIFSR_TRY(conv_unit_wgrad(c, lb, src_act(c, la), src_none(), c.f(w.g[lb]), grads, k == 2));
       SIFSR_TRY(conv_unit_dgrad(c, lb, c.f(w.g[lb]), c.f(w.g[la]), nt.L[la].cout, nt.L[lb].cin, nullptr, 0, nullptr, la, &rows_a, k == 2));
@@ -699,8 +701,20 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   static const int enc_prev[3] = {L_IN3, L_D1C, L_D2C};
   static const int enc_a[3] = {L_D1A, L_D2A, L_D3A}, enc_b[3] = {L_D1B, L_D2B, L_D3B}, enc_c[3] = {L_D1C, L_D2C, L_D3C};
   static const int pc[3] = {16, 32, 64};
+  static const int early_reduce = getenv("SIFSR_DBG_EARLY_REDUCE") ? atoi(getenv("SIFSR_DBG_EARLY_REDUCE")) : 1;
   for (int k = 2; k >= 0; --k) {
     const int la = enc_a[k], lb = enc_b[k], lc = enc_c[k], lp = enc_prev[k];
+    if (k == 0 && c.side != nullptr && early_reduce) {
+      // the slabs of every layer so far (decoder, db3, db2: all the 32 / 64-channel ones, 9/10 of the slab bytes) are reduced NOW on the
+      // second stream, between its weight gradients, instead of in the one batch at the end: there the 370 MB reduction ran beside the
+      // first layer's weight gradient -- the last kernel of the chain, HBM-bound like it -- and set the end of the step
+      if (last_fused >= 0) {
+        if (hipStreamWaitEvent(c.side->s, c.side->ev[last_fused], 0) != hipSuccess) return SIFSR_ERR_ARG;
+        lane_guard.forked = true;
+      }
+      SIFSR_TRY(finish_wgrads(c.side->s));
+      njobs = 0; nxjobs = 0;
+    }
     // lastconv: input R_k = P_k + relu(bn(y_b)); its gradient is both g(a_b) and part of g(P_k).
     // y_c also feeds the next pooling stage (k < 2): that AvgPool adjoint (of gP[k+1], computed in the previous
     // iteration) is folded into this BatchNorm backward instead of a separate accumulate pass over g[lc].
