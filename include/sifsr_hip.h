@@ -158,6 +158,16 @@ SIFSR_API int sifsr_conv3x3_bwd16(const float* x, const float* x_scale, const fl
                                   const float* coef_f, float* border, const float* wdgrad, const float* wwd, float* gin,
                                   const float* addend, const float* bn_y, const float* bn_scale, const float* bn_shift,
                                   float* bn_partials, float* scratch, float* dw, int B, int H, int W, void* stream);
+/* The same for a layer whose output also feeds a pooling stage (inbloc.bloc.3 -> AvgPool2d(2,2), model.py:597, :528): its upstream
+ * gradient is g (the decoder skip's) + the pooling adjoint of the half-resolution gradient pool_gp ((B, H/2, W/2, 16) NHWC), i.e.
+ * g_eff[y][x] = g[y][x] + 0.25 * pool_gp[y/2][x/2], formed while staging -- the BatchNorm-backward reduction that precedes it in
+ * ModelB_2's backward takes its sums from the same g_eff on the fly and no longer stores it (a 16-channel tensor write; the single-op
+ * entry sifsr_bn_relu_bwd_coef with gpool still writes g_eff back into g).  y, coef_f, border required; coef_f must come from g_eff. */
+SIFSR_API int sifsr_conv3x3_bwd16_pool(const float* x, const float* x_scale, const float* x_shift, const float* g,
+                                       const float* pool_gp, const float* y, const float* coef_f, float* border,
+                                       const float* wdgrad, const float* wwd, float* gin, const float* bn_y,
+                                       const float* bn_scale, const float* bn_shift, float* bn_partials, float* scratch,
+                                       float* dw, int B, int H, int W, void* stream);
 /* The same for the LAST 16 -> 16 layer, ub3.convbloc.bloc.3, whose output feeds outlay (Conv2d(16, 1, 3, padding_mode="replicate"),
  * model.py:605): the upstream gradient g = outlay^T(dsr) is never stored -- each staged pixel recomputes it from a 20x20 tile of
  * dsr = d loss / d sr ([B][H][W] fp32, in every storage mode) and w_out ([1][16][3][3]), replicate-padding adjoint included; the rest

@@ -305,6 +305,22 @@ int sifsr_conv3x3_bwd16(const float* x, const float* x_scale, const float* x_shi
   a.B = B; a.H = H; a.W = W;
   return bwd16_op(a, y ? border : g, wdgrad, bn_partials, scratch, dw, stream);
 }
+// ... of a layer that also feeds a pooling stage (inbloc.bloc.3): the upstream gradient is g + 0.25 * pool_gp[b][y/2][x/2] (the AvgPool2d(2,2)
+// adjoint of the half-resolution gradient pool_gp, 16 channels), added while staging; otherwise sifsr_conv3x3_bwd16 with y != NULL, no addend
+int sifsr_conv3x3_bwd16_pool(const float* x, const float* x_scale, const float* x_shift, const float* g, const float* pool_gp,
+                             const float* y, const float* coef_f, float* border, const float* wdgrad, const float* wwd, float* gin,
+                             const float* bn_y, const float* bn_scale, const float* bn_shift, float* bn_partials, float* scratch,
+                             float* dw, int B, int H, int W, void* stream) {
+  if (!conv3x3_bwd16_applies(B, H, W)) return SIFSR_ERR_SHAPE;
+  if (!x || !g || !pool_gp || !y || !coef_f || !border || !wdgrad || !wwd || !gin || !scratch || !dw) return SIFSR_ERR_ARG;
+  if (bn_partials != nullptr && (!bn_y || !bn_scale || !bn_shift)) return SIFSR_ERR_ARG;
+  Bwd16Args a;
+  a.x = x; a.x_scale = x_scale; a.x_shift = x_shift; a.g = g; a.pool_gp = pool_gp; a.y = y; a.coef = coef_f; a.dy_border = border;
+  a.wpack_wino = wwd; a.gin = gin;
+  if (bn_partials != nullptr) { a.bn_y = bn_y; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.stat_partials = bn_partials; }
+  a.B = B; a.H = H; a.W = W;
+  return bwd16_op(a, border, wdgrad, bn_partials, scratch, dw, stream);
+}
 // ... of the LAST 16 -> 16 layer (ub3.convbloc.bloc.3): the upstream gradient g is the input gradient of outlay (Conv2d 16 -> 1,
 // replicate padding, model.py:605) and is recomputed while staging from dsr = d loss / d sr [B][H][W] (fp32) and w_out [1][16][3][3]
 int sifsr_conv3x3_bwd16_tail(const float* x, const float* x_scale, const float* x_shift, const float* dsr, const float* w_out,

@@ -112,6 +112,9 @@ struct Bwd16Args {
   float* slabs;                    // out: conv3x3_bwd16_grid() weight-gradient slabs of 16 * 256 floats (Winograd domain,
                                    //   the layout of conv_wgrad_wino.hip; reduce with launch_wgrad_wino_finish, nblk = grid)
   int B, H, W;
+  const float* pool_gp = nullptr;  // with y (not the tail): g_eff = g + 0.25 * pool_gp[b][y/2][x/2] is formed while staging -- the AvgPool2d(2,2)
+                                   //   adjoint of the half-resolution gradient (16 channels, H/2 x W/2) of a layer that also feeds a pooling stage
+                                   //   (inbloc.bloc.3); the BatchNorm-backward reduction then need not write the completed gradient back
   int store_dz = 0;                // with stat_partials: gin is stored MASKED, dz = gin * [bn_y * scale + shift > 0] -- what the layer below's
                                    //   BatchNorm backward consumes; for a layer below whose only other consumer is the linear form of its
                                    //   weight gradient (inbloc.bloc.0: edge_conv.hip conv_in_dz_wgrad_kernel)

@@ -71,9 +71,11 @@ static __device__ __forceinline__ int xslot(int i) { return (i >> 2) + 4 * (i & 
 // recomputed per staged pixel from a 20x20 tile of d loss / d sr (9 LDS reads, 36 FMAs per pixel and channel quad) instead of
 // being written to and read back from HBM by tail_bwd_apply_kernel (fused_edges.hip).
 // HS: every activation tensor (x, g, y, gin, addend, the border scratch) is stored as bf16
-template <int DYM, bool HS>
+// POOL (DYM == 1): the upstream gradient is g + 0.25 * pool_gp[y/2][x/2] (Bwd16Args::pool_gp), added while staging
+template <int DYM, bool HS, bool POOL = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a, const int ntiles, const int lgx, const int lgy) {
   constexpr bool DYF = DYM != 0, TAIL = DYM == 2;
+  static_assert(!POOL || DYM == 1, "the pooling adjoint joins the (g, y) form");
   __shared__ float4 dyq[2][DYQ_F4];                       // dL/dy halo, [cout quad][pixel (even | odd columns)][4]
   __shared__ __align__(16) float dyp[2][DYP_F + 16];      // dL/dy core, channel planes
   __shared__ __align__(16) float xp[2][XP_F + 16];        // a_in halo, channel planes
@@ -130,6 +132,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
     lx[it] = cg * XPS + p;
   }
   const bool slot2 = pslot + 256 < 324;
+  // POOL: low-resolution pixel of the slot relative to (tile row * 8 - 1, tile column * 8 - 1): ((spy + 1) >> 1, (spx + 1) >> 1)
+  const int H2 = H >> 1, W2 = W >> 1;
+  const __amdgpu_buffer_rsrc_t rgp = mk_rsrc(POOL ? a.pool_gp : a.x, POOL ? (npix >> 2) * PXB : 4u);
+  unsigned relp[3];
+#pragma unroll
+  for (int it = 0; it < 3; ++it) relp[it] = (unsigned)(((spy[it] + 1) >> 1) * W2 + ((spx[it] + 1) >> 1)) * 64u + (unsigned)cg * 16u;
+  float4 pgp[POOL ? 3 : 1];
   float4 csc = make_float4(0.f, 0.f, 0.f, 0.f), csh = csc, ck1 = csc, ck0 = csc;
   if (DYF) { csc = ld4(a.coef + 4 * cg); csh = ld4(a.coef + 16 + 4 * cg); ck1 = ld4(a.coef + 32 + 4 * cg); ck0 = ld4(a.coef + 48 + 4 * cg); }
   const bool xraw = a.x_scale == nullptr;
@@ -162,6 +171,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
         if (!TAIL) pg[it] = al4<HS>(rg, rel[it], soff);
         if (DYF) py[it] = al4<HS>(ry, rel[it], soff);
         px_[it] = al4<HS>(rx, rel[it], soff);
+        if (POOL) pgp[it] = al4<HS>(rgp, relp[it], (unsigned)((st_b * H2 + st_ty * 8 - 1) * W2 + st_tx * 8 - 1) * 64u);
       }
     } else {
 #pragma unroll
@@ -172,6 +182,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
         if (!TAIL) pg[it] = al4<HS>(rg, inside ? pc : OOB, 0u);   // zero padding of dL/dy
         if (DYF) py[it] = al4<HS>(ry, inside ? pc : OOB, 0u);
         px_[it] = al4<HS>(rx, pc, 0u);                        // replicate padding of the forward input
+        if (POOL) pgp[it] = al4<HS>(rgp, inside ? (unsigned)((st_b * H2 + (gy >> 1)) * W2 + (gx >> 1)) * 64u + (unsigned)cg * 16u : OOB, 0u);
       }
     }
   };
@@ -217,6 +228,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
           gh = __builtin_elementwise_fma((f32x2){wq.z, wq.w}, (f32x2){S[t], S[t]}, gh);
         }
         v = make_float4(gl[0], gl[1], gh[0], gh[1]);
+      }
+      if (POOL) {
+        const float4 q = pgp[it];
+        v.x = fmaf(0.25f, q.x, v.x); v.y = fmaf(0.25f, q.y, v.y); v.z = fmaf(0.25f, q.z, v.z); v.w = fmaf(0.25f, q.w, v.w);
       }
       if (DYF) {
         v = bn_bwd4(v, py[it], csc, csh, ck1, ck0);
@@ -546,6 +561,13 @@ int launch_conv3x3_bwd16(const Bwd16Args& a, hipStream_t s) {
   const int tx_ = a.W / 16, ty_ = a.H / 16, ntiles = a.B * tx_ * ty_;
   const int lgx = (pow2(tx_) && pow2(ty_)) ? lg(tx_) : -1, lgy = lgx >= 0 ? lg(ty_) : -1;
   const dim3 grid(conv3x3_bwd16_grid(a.B, a.H, a.W)), block(512);
+  if (a.pool_gp != nullptr && (tail || a.y == nullptr)) return SIFSR_ERR_ARG;
+  if (a.pool_gp != nullptr) {
+    if (a.half) hipLaunchKernelGGL((conv3x3_bwd16_kernel<1, true, true>), grid, block, 0, s, a, ntiles, lgx, lgy);
+    else hipLaunchKernelGGL((conv3x3_bwd16_kernel<1, false, true>), grid, block, 0, s, a, ntiles, lgx, lgy);
+    SIFSR_LAUNCH_CHECK();
+    return SIFSR_OK;
+  }
   if (a.half) {
     if (tail) hipLaunchKernelGGL((conv3x3_bwd16_kernel<2, true>), grid, block, 0, s, a, ntiles, lgx, lgy);
     else if (a.y != nullptr) hipLaunchKernelGGL((conv3x3_bwd16_kernel<1, true>), grid, block, 0, s, a, ntiles, lgx, lgy);

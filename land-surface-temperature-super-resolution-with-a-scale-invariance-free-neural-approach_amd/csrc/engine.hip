@@ -348,7 +348,8 @@ int conv_unit_fwd(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, int training, flo
 // layer above (conv_unit_dgrad with bn_layer), so the reduce pass over (g, y) is skipped.
 // border_rows: rows the border-fold kernel added to bpart (default: those of a 16-channel dgrad); 0 when the sums came
 // from the upsample adjoint (resample.hip), which has no border part.
-int bn_unit_bwd(const Ctx& c, int l, float* g, float* grads, const float* gp = nullptr, int fused_stats = 0, int border_rows = -1) {
+int bn_unit_bwd(const Ctx& c, int l, float* g, float* grads, const float* gp = nullptr, int fused_stats = 0, int border_rows = -1,
+                bool writeback = true) {   // writeback = false (with gp): the consumer adds the pooling adjoint itself while staging
   const LayerInfo& L = c.nt.L[l];
   const int lh = c.lvH(L.level), lw = c.lvW(L.level);
   const size_t npix = c.lay.npix[L.level];
@@ -363,7 +364,7 @@ int bn_unit_bwd(const Ctx& c, int l, float* g, float* grads, const float* gp = n
   size_t nb = npix / 256;
   const int nblk = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
   SIFSR_TRY(launch_bn_bwd_reduce(g, c.f(c.lay.y[l]), c.scale(l), c.shift(l), c.f(c.lay.mean) + L.ch_off, c.f(c.lay.invstd) + L.ch_off,
-                                 L.cout, npix, c.f(c.lay.partials), nblk, c.s, gp, lh, lw, gp ? g : nullptr));
+                                 L.cout, npix, c.f(c.lay.partials), nblk, c.s, gp, lh, lw, (gp && writeback) ? g : nullptr));
   return launch_bn_bwd_finalize(c.f(c.lay.partials), nblk, L.cout, (double)npix, c.scale(l), c.f(c.lay.mean) + L.ch_off,
                                 c.f(c.lay.invstd) + L.ch_off, grads + L.gamma_off, grads + L.beta_off,
                                 reinterpret_cast<double*>(c.f(c.lay.coef)), c.s, c.shift(l), c.params + L.beta_off, coef_f);
@@ -482,7 +483,7 @@ bool bwd16_usable(const Ctx& c, int l, ConvSrc s0) {
 // dy_mode 0: `dy` is dL/dy itself.  1: `dy` is g = dL/d relu(bn(y_l)), dL/dy formed while staging.  2 (l = ub3.convbloc.bloc.3): `dy` is
 // d loss / d sr and g the input gradient of outlay, recomputed while staging (no tail_bwd_apply pass).
 int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin, const float* addend, int bn_layer, int* stat_rows,
-                    int dy_mode, bool* applied, bool store_dz = false) {
+                    int dy_mode, bool* applied, bool store_dz = false, const float* pool_gp = nullptr) {
   const LayerInfo& L = c.nt.L[l];
   *applied = false;
   if (stat_rows) *stat_rows = 0;
@@ -507,7 +508,8 @@ int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin
   a.B = c.B; a.H = lh; a.W = lw;
   a.half = c.bf16;
   if (store_dz && !fuse) return SIFSR_ERR_ARG;
-  a.store_dz = store_dz ? 1 : 0;   // gin leaves the kernel (and the border fold) multiplied by the ReLU mask of the layer below
+  a.store_dz = store_dz ? 1 : 0;
+  a.pool_gp = pool_gp;   // gin leaves the kernel (and the border fold) multiplied by the ReLU mask of the layer below
   {
     ProfScope ps(l, 2, c.s);     // one launch = both passes of the layer: timed as its input-gradient selection
     SIFSR_TRY(launch_conv3x3_bwd16(a, c.s));
@@ -743,10 +745,16 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   }
 
   // inbloc
-  SIFSR_TRY(bn_unit_bwd(c, L_IN3, c.f(w.g[L_IN3]), grads, c.f(w.gP[0])));
+  // inbloc.bloc.3 also feeds the first pooling stage: its gradient is g (the decoder skip) + the AvgPool adjoint of gP[0].  Where the
+  // fused kernel runs it adds the adjoint while staging (a 67 MB read) and the reduction does not write the sum back (268 MB)
+  static const int pool_on_load_env = getenv("SIFSR_DBG_POOL_ON_LOAD") ? atoi(getenv("SIFSR_DBG_POOL_ON_LOAD")) : 1;
+  const bool pool_on_load = pool_on_load_env != 0 && bwd16_usable(c, L_IN3, src_act(c, L_IN0));
+  SIFSR_TRY(bn_unit_bwd(c, L_IN3, c.f(w.g[L_IN3]), grads, c.f(w.gP[0]), 0, -1, !pool_on_load));
   int rows_in0 = 0;
   bool fused_in3 = false;
-  SIFSR_TRY(conv_unit_bwd16(c, L_IN3, src_act(c, L_IN0), c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), nullptr, L_IN0, &rows_in0, 1, &fused_in3, head_linear));
+  SIFSR_TRY(conv_unit_bwd16(c, L_IN3, src_act(c, L_IN0), c.f(w.g[L_IN3]), c.f(w.g[L_IN0]), nullptr, L_IN0, &rows_in0, 1, &fused_in3, head_linear,
+                            pool_on_load ? c.f(w.gP[0]) : nullptr));
+  if (pool_on_load && !fused_in3) return SIFSR_ERR_ARG;
   if (head_linear && !fused_in3) return SIFSR_ERR_ARG;
   if (!fused_in3) SIFSR_TRY(conv_unit_wgrad(c, L_IN3, src_act(c, L_IN0), src_none(), c.f(w.g[L_IN3]), grads));
   // that was the last MFMA layer: all 16 layers' weight-gradient slabs -> OIHW gradients, one launch.  With the second

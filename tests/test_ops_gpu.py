@@ -808,6 +808,65 @@ def test_conv3x3_bwd16_tail_recomputes_the_outlay_input_gradient(L, shape):
     assert rel_err(gin, out["stored_g"][0]) < 2e-6 and rel_err(dw, out["stored_g"][1]) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(32, 48, 2), (128, 128, 8)])
+def test_conv3x3_bwd16_pool_adds_the_pooling_adjoint_while_staging(L, shape):
+    """inbloc.bloc.3: its output feeds the decoder skip AND AvgPool2d(2,2); the upstream gradient is g + pool^T(gp).  The pooled entry
+    (g and gp given separately) must equal sifsr_conv3x3_bwd16 fed the completed gradient -- gin, dW, border dL/dy, BatchNorm sums."""
+    H, W, B = shape
+    C = 16
+    rs = np.random.RandomState(777 + H)
+    x = rnd(rs, B, C, H, W)
+    xs = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)); xsh = rnd(rs, C, scale=0.3)
+    w = rnd(rs, C, C, 3, 3, scale=(2.0 / (9 * C)) ** 0.5)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)); beta = rnd(rs, C, scale=0.5)
+    g = rnd(rs, B, C, H, W); gp = rnd(rs, B, C, H // 2, W // 2)
+    wf = torch.empty(9 * C * C, device="cuda"); wd = torch.empty(4 * 9 * C * C, device="cuda")
+    L.call("sifsr_pack_conv_weights", dev(w), C, C, wf, wd, S())
+    wwf = torch.empty(16 * C * C, device="cuda"); wwd = torch.empty(16 * C * C, device="cuda")
+    L.call("sifsr_pack_conv_weights_wino", dev(w), C, C, wwf, wwd, S())
+    dx, dxs, dxsh = dev(nhwc(x)), dev(xs), dev(xsh)
+    y = torch.empty(B, H, W, C, device="cuda")
+    nblk = L.call("sifsr_conv3x3_stat_blocks", B, H, W, C)
+    part = torch.empty(nblk, C, 2, device="cuda")
+    L.call("sifsr_conv3x3_fwd", dx, C, dxs, dxsh, None, 0, None, None, wf, y, C, part, B, H, W, S())
+    mean, invstd, scale, shift = (torch.empty(C, device="cuda") for _ in range(4))
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    L.call("sifsr_bn_finalize", part, nblk, C, float(B * H * W), dev(gamma), dev(beta), rm, rv, 0.1, 1e-5, mean, invstd, scale, shift, S())
+    npix = B * H * W
+    nb = max(1, min(1024, npix // 256))
+    partials = torch.empty(max(nb, 1024) * C * 2, device="cuda")
+    dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    coef = torch.empty(3 * C, dtype=torch.float64, device="cuda"); coef_f = torch.empty(4 * C, device="cuda")
+    dg, dgp = dev(nhwc(g)), dev(nhwc(gp))
+    g_eff = dg.clone()                                     # completed in place by the reduction (the single-op entry writes it back)
+    L.call("sifsr_bn_relu_bwd_coef", g_eff, y, scale, shift, mean, invstd, dev(beta), C, npix, partials, nb, dgam, dbet, coef, coef_f, dgp, H, W, S())
+    torch.cuda.synchronize()
+    ref_eff = g + 0.25 * gp.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    assert rel_err(nchw(g_eff.cpu()), ref_eff) < 1e-6
+    rows = L.call("sifsr_conv3x3_bwd16_stat_rows", B, H, W)
+    out = {}
+    for kind in ("pool", "completed"):
+        scratch = torch.empty(L.call("sifsr_conv3x3_bwd16_scratch_floats", B, H, W), device="cuda")
+        gin = torch.full((B, H, W, C), float("nan"), device="cuda")
+        dw = torch.full((C, C, 3, 3), float("nan"), device="cuda")
+        border = torch.full((B, H, W, C), float("nan"), device="cuda")
+        bnp = torch.full((rows, C, 2), float("nan"), device="cuda")
+        if kind == "pool":
+            L.call("sifsr_conv3x3_bwd16_pool", dx, dxs, dxsh, dg, dgp, y, coef_f, border, wd, wwd, gin, dx, dxs, dxsh, bnp, scratch, dw,
+                   B, H, W, S())
+        else:
+            L.call("sifsr_conv3x3_bwd16", dx, dxs, dxsh, g_eff, y, coef_f, border, wd, wwd, gin, None, dx, dxs, dxsh, bnp, scratch, dw,
+                   B, H, W, S())
+        torch.cuda.synchronize()
+        out[kind] = (gin.clone(), dw.clone(), border.clone(), bnp.double().sum(dim=0).cpu())
+    a_, b_ = out["pool"], out["completed"]
+    assert rel_err(a_[0], b_[0]) < 2e-6 and rel_err(a_[1], b_[1]) < 2e-5
+    edge = torch.zeros(H, W, dtype=torch.bool); edge[0] = edge[-1] = True; edge[:, 0] = edge[:, -1] = True
+    ba, bb = nchw(a_[2].cpu()), nchw(b_[2].cpu())
+    assert torch.isnan(ba[:, :, ~edge]).all() and rel_err(ba[:, :, edge], bb[:, :, edge]) < 2e-6
+    assert rel_err(a_[3], b_[3]) < 1e-5
+
+
 def test_conv3x3_bwd16_rejects_other_shapes(L):
     assert L.call("sifsr_conv3x3_bwd16_stat_rows", 2, 24, 32) == 0 and L.call("sifsr_conv3x3_bwd16_scratch_floats", 2, 16, 16) == 0
     t = torch.zeros(2, 24, 32, 16, device="cuda")
