@@ -131,7 +131,8 @@ SIFSR_API int sifsr_conv3x3_wgrad_fused(const float* src0, int C0, const float* 
 /* Winograd F(3x3, 2x2) form of the weight gradient (fp32, even H and W): 16 instead of 36 matrix-core products per 2x2
  * output patch and channel pair; every lane transforms its own (patch, channel) operand in registers from channel-plane
  * tiles in LDS.  y == coef_f == NULL: g is dL/dy itself; otherwise as sifsr_conv3x3_wgrad_fused.  Results differ from
- * sifsr_conv3x3_wgrad by fp32 rounding only (slabs are reduced and transformed in float64). */
+ * sifsr_conv3x3_wgrad by fp32 rounding only (each workgroup applies the output transform A^T M A to its accumulators and writes a
+ * tap-domain slab of 9 values per weight pair; the slabs are reduced in float64 in a fixed order). */
 SIFSR_API size_t sifsr_conv3x3_wgrad_wino_scratch_floats(int cin, int cout, int nblk);
 SIFSR_API int sifsr_conv3x3_wgrad_wino(const float* src0, int C0, const float* scale0, const float* shift0,
                                        const float* src1, int C1, const float* scale1, const float* shift1,
@@ -148,7 +149,7 @@ SIFSR_API int sifsr_conv3x3_wgrad_wino(const float* src0, int C0, const float* s
  *   bn_partials != NULL: gin is the gradient w.r.t. relu(bn(bn_y)) of the layer below -- bn_y, bn_scale, bn_shift must BE x, x_scale,
  *   x_shift (the layer below is the layer whose raw output is this layer's input) -- and its BatchNorm-backward sums are emitted as sifsr_conv3x3_bwd16_stat_rows() rows of [16][2]
  *   (sum dz, sum dz*y per channel; dz = gin*[bn_y*scale+shift > 0]); add the rows up.  Not together with addend.
- *   scratch: sifsr_conv3x3_bwd16_scratch_floats() floats (weight-gradient slabs + their float64 sum).
+ *   scratch: sifsr_conv3x3_bwd16_scratch_floats() floats (one tap-domain weight-gradient slab per workgroup, reduced in float64).
  *   After sifsr_set_op_storage_bf16(1) the activation tensors (x, g, y, border, gin, addend, bn_y) are NHWC bf16 -- what the model's
  *   bf16 mode runs for these layers: half the bytes, fp32 arithmetic (fp32 MFMAs in the Winograd domain; the border fold rounds
  *   its operands to bf16 as the bf16 input-gradient kernel does). */

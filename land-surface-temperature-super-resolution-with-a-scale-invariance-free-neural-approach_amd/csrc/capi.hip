@@ -243,8 +243,8 @@ int sifsr_conv3x3_wgrad_fused(const float* src0, int C0, const float* scale0, co
   return launch_wgrad_reduce(scratch, nblk, cin, cout, wgrad_nbi_chunk(a, cin), dw, S(stream));
 }
 
-// Winograd F(3x3, 2x2) form.  scratch = [nblk slabs of 16*cin*cout floats | 16*cin*cout doubles]
-size_t sifsr_conv3x3_wgrad_wino_scratch_floats(int cin, int cout, int nblk) { return (size_t)(nblk + 2) * 16 * cin * cout; }
+// Winograd F(3x3, 2x2) form.  scratch = nblk slabs of 9*cin*cout floats (the kernel applies the output transform before it writes them)
+size_t sifsr_conv3x3_wgrad_wino_scratch_floats(int cin, int cout, int nblk) { return (size_t)nblk * 9 * cin * cout; }
 
 int sifsr_conv3x3_wgrad_wino(const float* src0, int C0, const float* scale0, const float* shift0, const float* src1, int C1,
                              const float* scale1, const float* shift1, const float* g, const float* y, const float* coef_f,
@@ -262,9 +262,7 @@ int sifsr_conv3x3_wgrad_wino(const float* src0, int C0, const float* scale0, con
   if (!conv3x3_wgrad_use_wino(a, cin, cout)) return SIFSR_ERR_SHAPE;
   int rc = launch_conv3x3_wgrad_wino(a, cin, cout, nblk, S(stream));
   if (rc) return rc;
-  WgradReduceJob j;
-  j.slab_off = 0; j.nblk = nblk; j.cin = cin; j.cout = cout; j.nbi_chunk = wgrad_wino_nbi_chunk(a, cin); j.w_off = 0;
-  return launch_wgrad_wino_finish(scratch, &j, 1, reinterpret_cast<double*>(scratch + (size_t)nblk * 16 * cin * cout), dw, S(stream));
+  return launch_wgrad_reduce(scratch, nblk, cin, cout, wgrad_wino_nbi_chunk(a, cin), dw, S(stream));
 }
 
 // Input gradient AND weight gradient of a 16 -> 16 channel layer from one read of its operands (conv_bwd16.hip).
@@ -272,7 +270,7 @@ int sifsr_conv3x3_bwd16_stat_rows(int B, int H, int W) {
   return conv3x3_bwd16_applies(B, H, W) ? conv3x3_bwd16_grid(B, H, W) + dgrad_border_waves(B, H, W, 16) : 0;
 }
 size_t sifsr_conv3x3_bwd16_scratch_floats(int B, int H, int W) {
-  return conv3x3_bwd16_applies(B, H, W) ? ((size_t)conv3x3_bwd16_grid(B, H, W) + 2) * 16 * 256 : 0;
+  return conv3x3_bwd16_applies(B, H, W) ? (size_t)conv3x3_bwd16_grid(B, H, W) * 9 * 256 : 0;
 }
 static int bwd16_op(Bwd16Args a, const float* dy_edge, const float* wdgrad, float* bn_partials, float* scratch, float* dw, void* stream) {
   const int B = a.B, H = a.H, W = a.W;
@@ -286,9 +284,7 @@ static int bwd16_op(Bwd16Args a, const float* dy_edge, const float* wdgrad, floa
                                bn_partials ? a.bn_y : nullptr, bn_partials ? a.bn_scale : nullptr, bn_partials ? a.bn_shift : nullptr,
                                bn_partials ? bn_partials + (size_t)grid * 32 : nullptr);
   if (rc) return rc;
-  WgradReduceJob j;
-  j.slab_off = 0; j.nblk = grid; j.cin = 16; j.cout = 16; j.nbi_chunk = 1; j.w_off = 0;
-  return launch_wgrad_wino_finish(scratch, &j, 1, reinterpret_cast<double*>(scratch + (size_t)grid * 16 * 256), dw, S(stream));
+  return launch_wgrad_reduce(scratch, grid, 16, 16, 1, dw, S(stream));
 }
 int sifsr_conv3x3_bwd16(const float* x, const float* x_scale, const float* x_shift, const float* g, const float* y,
                         const float* coef_f, float* border, const float* wdgrad, const float* wwd, float* gin,

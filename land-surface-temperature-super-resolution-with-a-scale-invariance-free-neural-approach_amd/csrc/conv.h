@@ -88,7 +88,27 @@ int launch_wgrad_reduce_batched(const float* ws, const WgradReduceJob* jobs, int
 bool conv3x3_wgrad_use_wino(const WgradArgs& a, int cin, int cout);
 int wgrad_wino_nbi_chunk(const WgradArgs& a, int cin);   // its Cin chunking (a 32-channel chunk may span the two sources)
 int launch_conv3x3_wgrad_wino(const WgradArgs& a, int cin, int cout, int nblk, hipStream_t s);
-int launch_wgrad_wino_finish(const float* ws, const WgradReduceJob* jobs, int njobs, double* mbuf, float* grads, hipStream_t s);
+// Output transform of the Winograd F(3x3, 2x2) weight gradient, dW = A^T M A per (cout, cin) pair with A^T = [[1, .5, .5, 0],
+// [0, .5, -.5, 0], [0, .5, .5, 1]]: lane-local (a lane holds the same pairs for all 16 xi), applied by the producing kernels to their
+// accumulators before the slab is written -- slabs are then 9 instead of 16 values per pair, in the tap-domain kernel's layout
+// ([chunk][nbo][nbi][tap][lane][4]), and the tap-domain slab reduction (launch_wgrad_reduce*) serves both.
+template <typename V4, typename GET>
+static __device__ __forceinline__ void wino_wgrad_taps(GET&& m, V4 (&tap)[9]) {   // m(xi) -> V4 (f32x4), xi = 4 u + v
+  V4 t[3][4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const V4 m1 = m(4 + v), m2 = m(8 + v);
+    t[0][v] = m(v) + 0.5f * (m1 + m2);
+    t[1][v] = 0.5f * (m1 - m2);
+    t[2][v] = 0.5f * (m1 + m2) + m(12 + v);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    tap[3 * i + 0] = t[i][0] + 0.5f * (t[i][1] + t[i][2]);
+    tap[3 * i + 1] = 0.5f * (t[i][1] - t[i][2]);
+    tap[3 * i + 2] = 0.5f * (t[i][1] + t[i][2]) + t[i][3];
+  }
+}
 
 // Input gradient AND weight gradient of a 16 -> 16 channel layer from one read of its operands (conv_bwd16.hip): H, W multiples
 // of 16, every tensor NHWC with exactly 16 channels.
@@ -110,7 +130,7 @@ struct Bwd16Args {
   const float* bn_shift = nullptr;
   float* stat_partials = nullptr;  // ... as [conv3x3_bwd16_grid()][16][2]
   float* slabs;                    // out: conv3x3_bwd16_grid() weight-gradient slabs of 16 * 256 floats (Winograd domain,
-                                   //   the layout of conv_wgrad_wino.hip; reduce with launch_wgrad_wino_finish, nblk = grid)
+                                   //   tap domain after the in-kernel output transform: 9 * 256 floats each; reduce with launch_wgrad_reduce*, nblk = grid)
   int B, H, W;
   const float* pool_gp = nullptr;  // with y (not the tail): g_eff = g + 0.25 * pool_gp[b][y/2][x/2] is formed while staging -- the AvgPool2d(2,2)
                                    //   adjoint of the half-resolution gradient (16 channels, H/2 x W/2) of a layer that also feeds a pooling stage

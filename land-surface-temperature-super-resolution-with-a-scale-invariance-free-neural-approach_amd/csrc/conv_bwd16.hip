@@ -486,8 +486,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
       }
     });
     // ---- the four weight-gradient waves' accumulators are added up through LDS in a fixed order (waves 1, 2, 3 into wave 0;
-    // the input-gradient waves execute the matching barriers), then ONE slab per workgroup, [xi][lane][4] (the layout of
-    // conv_wgrad_wino.hip for one block pair)
+    // the input-gradient waves execute the matching barriers), then ONE slab per workgroup, [tap][lane][4] (the layout of
+    // both weight-gradient kernel families for one block pair)
     float4* const comb = dyq[0];
     __syncthreads();                                      // every read of the tile buffers is done
     for (int w = 1; w < 4; ++w) {
@@ -502,10 +502,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bwd16_kernel(const Bwd16Args a
       }
       __syncthreads();
     }
-    if (wave == 0) {
-      float* slab = a.slabs + (size_t)blockIdx.x * (16 * 256);
+    if (wave == 0) {   // the output transform per lane (conv.h wino_wgrad_taps): a tap-domain slab, 9 * 256 floats
+      float* slab = a.slabs + (size_t)blockIdx.x * (9 * 256);
+      f32x4 tap[9];
+      wino_wgrad_taps([&](int xi) { return acc[xi]; }, tap);
 #pragma unroll
-      for (int tt = 0; tt < 16; ++tt) st4(slab + tt * 256 + lane * 4, make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]));
+      for (int tt = 0; tt < 9; ++tt) st4(slab + tt * 256 + lane * 4, make_float4(tap[tt][0], tap[tt][1], tap[tt][2], tap[tt][3]));
     }
   }
   // ---- BatchNorm-backward partials of the layer below: one row per workgroup

@@ -29,7 +29,6 @@ struct WsLayout {
   size_t gram;                            // Gram matrix / sums of the input patches for the first layer's weight gradient (edge_conv.hip)
   size_t slab_l[SIFSR_NUM_BN_LAYERS];     // wgrad per-workgroup partial dW of every MFMA layer (reduced together at the end)
   size_t slab_cap[SIFSR_NUM_BN_LAYERS];   // ... and the size of each region in floats (checked against the grid actually launched)
-  size_t wgm;                             // the reduced Winograd-domain weight gradients (float64, 16 per weight pair) before the output transform
   size_t total;
 };
 

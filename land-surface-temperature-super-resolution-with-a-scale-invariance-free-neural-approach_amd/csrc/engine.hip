@@ -134,24 +134,21 @@ int sifsr_layout(int B, int H, int W, int training, WsLayout* o) {
     w.slabs = take(1024 * 288);   // edge-layer partials
     w.gram = take(conv_in_gram_scratch_floats());
     w.slab_l[0] = 0; w.slab_cap[0] = 0;
-    size_t wino_pairs = 0;
     for (int l = 1; l < SIFSR_NUM_BN_LAYERS; ++l) {
       const int lvh = H >> nt.L[l].level, lvw = W >> nt.L[l].level;
       const int ntiles = B * ((lvh + 7) / 8) * ((lvw + 15) / 16);
       // upper bound over chunkings (x-dim blocks * chunks <= blocks at one chunk)
-      // (16 values per weight pair: the Winograd F(3x3,2x2) form; the tap-domain form uses 9 of them)
+      // (9 values per weight pair: the Winograd F(3x3,2x2) kernels apply their output transform before they write a slab)
       // ... and over the two kernel families: the tap-domain grid scales with SIFSR_DBG_WGRAD_GRID_PCT, the Winograd one does not
       const int nb_tap = wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles, false), nb_wino = wgrad_blocks(nt.L[l].cin, nt.L[l].cout, 1, ntiles, true);
-      w.slab_cap[l] = (size_t)(nb_tap > nb_wino ? nb_tap : nb_wino) * 16 * nt.L[l].cin * nt.L[l].cout;
+      w.slab_cap[l] = (size_t)(nb_tap > nb_wino ? nb_tap : nb_wino) * 9 * nt.L[l].cin * nt.L[l].cout;
       // ... and the fused input + weight gradient kernel of the 16 -> 16 layers writes one slab per workgroup
       if (nt.L[l].cin == 16 && nt.L[l].cout == 16 && conv3x3_bwd16_applies(B, lvh, lvw)) {
-        const size_t need = (size_t)conv3x3_bwd16_grid(B, lvh, lvw) * 16 * 256;
+        const size_t need = (size_t)conv3x3_bwd16_grid(B, lvh, lvw) * 9 * 256;
         if (need > w.slab_cap[l]) w.slab_cap[l] = need;
       }
       w.slab_l[l] = take(w.slab_cap[l]);
-      wino_pairs += (size_t)nt.L[l].cin * nt.L[l].cout;
     }
-    w.wgm = take(2 * 16 * wino_pairs);
   }
   w.total = off;
   return SIFSR_OK;
@@ -171,8 +168,7 @@ struct Ctx {
   hipStream_t s;
   WgradReduceJob* jobs = nullptr;   // backward: slab reductions deferred to one batched launch
   int* njobs = nullptr;
-  WgradReduceJob* xjobs = nullptr;  // ... of the layers whose weight gradient ran in the Winograd domain
-  int* nxjobs = nullptr;
+  bool wino_wgrads = false;         // backward: the Winograd-domain weight-gradient kernels (and the fused 16 -> 16 kernel) may run
   int bf16 = 0;                     // 1: bf16 MFMA operands (config 5)
   struct SideLane* side = nullptr;  // backward: the weight gradients' own stream (nullptr = everything on s)
   bool* forked = nullptr;           // set once anything was enqueued on the side stream (SideLaneGuard)
@@ -391,11 +387,11 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
   a.ntiles = c.B * ((a.H + 7) / 8) * ((a.W + 15) / 16);
   a.bf16 = c.bf16;
   // Winograd F(3x3,2x2) where it is the faster form (measured per shape, tools/sweep_layers.sh)
-  const bool wino = c.xjobs != nullptr && wgrad_wino_policy(L.cin, L.cout) && conv3x3_wgrad_use_wino(a, L.cin, L.cout);
+  const bool wino = c.wino_wgrads && wgrad_wino_policy(L.cin, L.cout) && conv3x3_wgrad_use_wino(a, L.cin, L.cout);
   const int nbi = wino ? wgrad_wino_nbi_chunk(a, L.cin) : wgrad_nbi_chunk(a, L.cin);
   const int nblk = wgrad_blocks(L.cin, L.cout, L.cin / (16 * nbi), a.ntiles, wino);
   // every workgroup (x cin chunks) writes one slab of (16 | 9) * cin_chunk * cout floats into this layer's region
-  if ((size_t)nblk * (L.cin / (16 * nbi)) * (wino ? 16 : 9) * (16 * nbi) * L.cout > c.lay.slab_cap[l]) return SIFSR_ERR_WORKSPACE;
+  if ((size_t)nblk * (L.cin / (16 * nbi)) * 9 * (16 * nbi) * L.cout > c.lay.slab_cap[l]) return SIFSR_ERR_WORKSPACE;
   hipStream_t ws = c.s;
   if (c.side != nullptr && c.jobs != nullptr) {   // dy_l is complete on the main stream at this point
     if (hipEventRecord(c.side->ev[l], c.s) != hipSuccess || hipStreamWaitEvent(c.side->s, c.side->ev[l], 0) != hipSuccess)
@@ -409,7 +405,7 @@ int conv_unit_wgrad(const Ctx& c, int l, ConvSrc s0, ConvSrc s1, const float* dy
     else SIFSR_TRY(launch_conv3x3_wgrad(a, L.cin, L.cout, nblk, ws));
   }
   if (c.jobs != nullptr) {
-    WgradReduceJob& j = wino ? c.xjobs[(*c.nxjobs)++] : c.jobs[(*c.njobs)++];
+    WgradReduceJob& j = c.jobs[(*c.njobs)++];   // (both kernel families leave tap-domain slabs)
     j.slab_off = c.lay.slab_l[l]; j.nblk = nblk; j.cin = L.cin; j.cout = L.cout; j.nbi_chunk = nbi; j.w_off = L.w_off;
   } else {
     SIFSR_TRY(launch_wgrad_reduce(a.slabs, nblk, L.cin, L.cout, nbi, grads + L.w_off, c.s));
@@ -477,7 +473,7 @@ bool bwd16_usable(const Ctx& c, int l, ConvSrc s0) {
   // 14,450 against 15,900 patches/s on the bf16 step -- with half the bytes its fp32 matrix + transform work is the bottleneck,
   // while the separate bf16 kernels contract with 16x cheaper MFMAs.  SIFSR_BF16_BWD16=1 selects it for A/B.
   static const int bf16_fused = getenv("SIFSR_BF16_BWD16") ? atoi(getenv("SIFSR_BF16_BWD16")) : 0;
-  return L.cin == 16 && L.cout == 16 && (c.bf16 == 0 || bf16_fused) && c.xjobs != nullptr && wgrad_wino_policy(16, 16) && s0.C == 16 &&
+  return L.cin == 16 && L.cout == 16 && (c.bf16 == 0 || bf16_fused) && c.wino_wgrads && wgrad_wino_policy(16, 16) && s0.C == 16 &&
          s0.coff == 0 && conv3x3_bwd16_applies(c.B, c.lvH(L.level), c.lvW(L.level));
 }
 // dy_mode 0: `dy` is dL/dy itself.  1: `dy` is g = dL/d relu(bn(y_l)), dL/dy formed while staging.  2 (l = ub3.convbloc.bloc.3): `dy` is
@@ -492,7 +488,7 @@ int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin
   const bool dy_stored = dy_mode == 0;
   const bool fuse = bn_layer >= 0 && addend == nullptr && c.nt.L[bn_layer].cout == 16 && c.nt.L[bn_layer].level == L.level;
   const int grid = conv3x3_bwd16_grid(c.B, lh, lw);
-  if ((size_t)grid * 16 * 256 > c.lay.slab_cap[l] || (fuse && (size_t)grid * 32 > c.lay.partials_cap)) return SIFSR_ERR_WORKSPACE;
+  if ((size_t)grid * 9 * 256 > c.lay.slab_cap[l] || (fuse && (size_t)grid * 32 > c.lay.partials_cap)) return SIFSR_ERR_WORKSPACE;
   Bwd16Args a;
   a.x = s0.ptr; a.x_scale = s0.scale; a.x_shift = s0.shift;
   if (dy_mode == 2) { a.tail_dsr = dy; a.tail_w = c.params + c.nt.out_w_off; }
@@ -518,7 +514,7 @@ int conv_unit_bwd16(const Ctx& c, int l, ConvSrc s0, const float* dy, float* gin
   SIFSR_TRY(launch_dgrad_border_fix(dy_stored ? dy : a.dy_border, 16, wdg_f32, 16, gin, 16, 16, gin, 16, c.B, lh, lw, c.s, c.bf16,
                                     fuse ? a.bn_y : nullptr, fuse ? a.bn_scale : nullptr, fuse ? a.bn_shift : nullptr,
                                     fuse ? c.f(c.lay.bpart) : nullptr, a.store_dz));
-  WgradReduceJob& j = c.xjobs[(*c.nxjobs)++];
+  WgradReduceJob& j = c.jobs[(*c.njobs)++];
   j.slab_off = c.lay.slab_l[l]; j.nblk = grid; j.cin = 16; j.cout = 16; j.nbi_chunk = 1; j.w_off = L.w_off;
   if (c.side != nullptr && hipEventRecord(c.side->ev[l], c.s) != hipSuccess) return SIFSR_ERR_ARG;   // slabs of l complete
   *applied = true;
@@ -612,12 +608,9 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   WgradReduceJob jobs[16];
   int njobs = 0;
   c.jobs = jobs; c.njobs = &njobs;
-  WgradReduceJob xjobs[16];
-  int nxjobs = 0;
-  c.xjobs = xjobs; c.nxjobs = &nxjobs;
+  c.wino_wgrads = true;
   auto finish_wgrads = [&](hipStream_t st) -> int {
     if (njobs > 0) SIFSR_TRY(launch_wgrad_reduce_batched(ws, jobs, njobs, grads, st));
-    if (nxjobs > 0) SIFSR_TRY(launch_wgrad_wino_finish(ws, xjobs, nxjobs, reinterpret_cast<double*>(c.f(w.wgm)), grads, st));
     return SIFSR_OK;
   };
   // tiny problems are launch-latency-bound: the 17 event hand-offs cost more than the overlap returns (batch 1 at 256x256:
@@ -715,7 +708,7 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
         lane_guard.forked = true;
       }
       SIFSR_TRY(finish_wgrads(c.side->s));
-      njobs = 0; nxjobs = 0;
+      njobs = 0;
     }
     // lastconv: input R_k = P_k + relu(bn(y_b)); its gradient is both g(a_b) and part of g(P_k).
     // y_c also feeds the next pooling stage (k < 2): that AvgPool adjoint (of gP[k+1], computed in the previous
