@@ -696,13 +696,13 @@ int sifsr_engine_backward(const float* x, const float* dsr, const float* params,
   static const int enc_prev[3] = {L_IN3, L_D1C, L_D2C};
   static const int enc_a[3] = {L_D1A, L_D2A, L_D3A}, enc_b[3] = {L_D1B, L_D2B, L_D3B}, enc_c[3] = {L_D1C, L_D2C, L_D3C};
   static const int pc[3] = {16, 32, 64};
-  static const int early_reduce = getenv("SIFSR_DBG_EARLY_REDUCE") ? atoi(getenv("SIFSR_DBG_EARLY_REDUCE")) : 1;
+  static const int early_reduce = getenv("SIFSR_DBG_EARLY_REDUCE") ? atoi(getenv("SIFSR_DBG_EARLY_REDUCE")) : 3;   // 0: one batch at the end; 1: + one before db1; 2: + one after the decoder; 3: one per encoder stage
   for (int k = 2; k >= 0; --k) {
     const int la = enc_a[k], lb = enc_b[k], lc = enc_c[k], lp = enc_prev[k];
-    if (k == 0 && c.side != nullptr && early_reduce) {
-      // the slabs of every layer so far (decoder, db3, db2: all the 32 / 64-channel ones, 9/10 of the slab bytes) are reduced NOW on the
-      // second stream, between its weight gradients, instead of in the one batch at the end: there the 370 MB reduction ran beside the
-      // first layer's weight gradient -- the last kernel of the chain, HBM-bound like it -- and set the end of the step
+    if (c.side != nullptr && (early_reduce == 1 ? k == 0 : early_reduce == 2 ? (k == 0 || k == 2) : early_reduce == 3 ? true : false)) {
+      // the slabs of every layer so far are reduced NOW on the second stream, between its weight gradients (one batch per encoder
+      // stage), instead of in one batch at the end: there the whole reduction -- 370 MB then, HBM-bound -- ran beside the first
+      // layer's weight gradient, the last kernel of the chain and HBM-bound like it, and set the end of the step
       if (last_fused >= 0) {
         if (hipStreamWaitEvent(c.side->s, c.side->ev[last_fused], 0) != hipSuccess) return SIFSR_ERR_ARG;
         lane_guard.forked = true;
